@@ -1,0 +1,117 @@
+/*
+ * mcpt_oracle.h -- CPU restatement of Arieys/MonteCarloPathTracing's hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (libmcpt.so) never
+ * links, loads or calls anything in oracle/.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference checkout, e.g. MTPC/pathTracing.cpp:137).  All arithmetic is IEEE fp64
+ * in the reference's own operation order, compiled with -ffp-contract=off.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - Morton keys      : pinned bit-exactly against the reference's own "morton code.cpp"
+ *                        compiled from where it lies (oracle/_ref/libref_morton.so).
+ *   - PNG bytes        : pinned byte-exactly against the reference's svpng.inc (oracle/_ref).
+ *   - loader/BVH/traversal/shading: the reference TUs need glm, OpenCV and Eigen headers
+ *     that this image lacks, so they are unbuildable here; the reference ships no tests or
+ *     golden vectors.  The only reference outputs are the time-seeded renders under
+ *     result/*.png; the oracle is pinned STATISTICALLY against block means of those
+ *     (tests/golden/published_*.npz).  Bitwise parity of those stages: PARITY UNPINNED.
+ *
+ * Documented deviations from the reference (all needed for reproducibility / to avoid UB):
+ *   D1  RNG seam: the four time(NULL)-seeded static engines (pathTracing.cpp:5,32,68,169)
+ *       are replaced by a counter-based Philox4x32-10 keyed (seed; pixel, sample, depth, slot).
+ *   D2  stable sort of faces by Morton key (MTPC.cpp:44 uses unstable std::sort).
+ *   D3  samples of a pixel are accumulated serially in k order (pathTracing.cpp:303-319 is
+ *       an unordered OpenMP/mutex accumulation).
+ *   D4  '\r' is stripped from every input line (the shipped scenes are CRLF).
+ *   D5  virtual right children are skipped instead of aliased (pathTracing.cpp:368-371 /
+ *       BVH.cpp:99-104); ORC_TRACE_ALIAS reproduces the aliasing for even t.
+ *   D6  recursion depth of shade() is capped at ORC_MAX_DEPTH (reference: unbounded).
+ *   D7  texture row/col are clamped to the raster (reference: possible 1-past read).
+ *   D8  Ns/Ni default to 1 when absent from the .mtl (reference: uninitialised).
+ */
+#ifndef MCPT_ORACLE_H
+#define MCPT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_DEPTH 64
+#define ORC_PI 3.1415926          /* MTPC/pathTracing.h:11 */
+#define ORC_P_RR 0.6              /* MTPC/pathTracing.cpp:237 */
+
+typedef struct orc_scene orc_scene;
+
+typedef struct {
+    int t, Lc, Lv, Nc, Nv, Nr, Level;    /* MTPC/BVH.cpp:46-52 */
+} orc_bvh_info;
+
+typedef struct {
+    uint64_t rays_primary, rays_shadow, rays_bounce;
+    uint64_t box_tests, tri_tests, shade_calls, samples;
+    int max_depth;
+} orc_stats;
+
+/* ---- RNG seam (D1) ---- */
+void     orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double   orc_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t depth, uint32_t slot);
+
+/* ---- Morton key: MTPC/morton code.cpp:3-32 ---- */
+uint32_t orc_morton_code(float x, float y, float z);
+
+/* ---- scene: MTPC/sceneManagement.cpp:17-274, MTPC/MTPC.cpp:44, MTPC/BVH.cpp:37-132 ---- */
+/* prefix = path+filename without extension; texture_dir = where map_Kd rasters are looked up
+ * ("<texture_dir>/<map_Kd>.ppm", binary P6 holding the decoded RGB raster). */
+orc_scene* orc_scene_load(const char* prefix, const char* texture_dir, char* err, int errlen);
+void       orc_scene_free(orc_scene*);
+void       orc_scene_set_resolution(orc_scene*, int width, int height);
+
+int  orc_num_faces(const orc_scene*);
+int  orc_num_materials(const orc_scene*);
+int  orc_num_lights(const orc_scene*);
+void orc_get_camera(const orc_scene*, double cam[10], int wh[2]); /* eye,lookat,up,fovy */
+/* faces in .obj order: 9 v, 9 vn, 6 vt, 3 norm = 27 doubles per face */
+void orc_get_faces(const orc_scene*, double* geom27, int32_t* material, uint32_t* morton);
+/* sorted (leaf) order -> original .obj face index */
+void orc_get_leaf_order(const orc_scene*, int32_t* leaf_to_face);
+void orc_get_bvh_info(const orc_scene*, orc_bvh_info*);
+/* Nr nodes, compact level order; box layout = max_x,max_y,max_z,min_x,min_y,min_z (sceneManagement.h:165-171) */
+void orc_get_bvh_nodes(const orc_scene*, double* box6, int32_t* level, int32_t* leaf_face);
+int  orc_find_index(const orc_scene*, int i, int l);              /* MTPC/BVH.cpp:99-104 */
+/* material record: kd3 ks3 Ns Ni (8 doubles), flags: has_map, map_w, map_h, light_index(-1 if none) */
+void orc_get_material(const orc_scene*, int m, char name[64], double rec8[8], int32_t flags4[4]);
+void orc_get_light(const orc_scene*, int i, char name[64], double radiance[3], int32_t* material, double* total_area);
+
+/* ---- closest hit: MTPC/pathTracing.cpp:334-390 ---- */
+#define ORC_TRACE_REAL_ONLY 0
+#define ORC_TRACE_ALIAS     1   /* reproduce the virtual-child aliasing (even t only) */
+#define ORC_TRACE_FLAT      2   /* brute force over all leaves: own box + triangle test, no tree */
+/* rays: n x 6 (origin, direction).  face = original .obj index or -1; p,pn = n x 3 */
+void orc_trace_closest(const orc_scene*, const double* rays, int64_t n, int mode,
+                       int32_t* face, double* t, double* p, double* pn, orc_stats* st);
+
+/* ---- integrator: MTPC/pathTracing.cpp:137-331 ---- */
+/* radiance of one camera sample (pixel index = row*W+col, sample k) */
+void orc_sample_radiance(const orc_scene*, uint64_t seed, int row, int col, int k, double rgb[3], orc_stats* st);
+/* primary ray for a pixel, exactly as generateImg builds it (incl. the running-sum position) */
+void orc_primary_ray(const orc_scene*, int row, int col, double ray6[6]);
+/* render rows [row0,row1) x cols [col0,col1) into img (full H*W*3 layout, doubles; other pixels untouched).
+ * faithful_cost!=0 re-traces the primary ray and rebuilds light CDFs per call like the reference
+ * (same result, reference-like cost; used for the CPU baseline).  nthreads<=0 -> OpenMP default. */
+void orc_render(const orc_scene*, int spp, uint64_t seed, int row0, int row1, int col0, int col1,
+                int faithful_cost, int nthreads, double* img, orc_stats* st);
+
+/* ---- output: MTPC/MTPC.cpp:10-33, MTPC/svpng.inc:77-107 ---- */
+void orc_quantize(const double* img, int64_t n, uint8_t* rgb8);
+/* returns number of bytes written into out (capacity cap), or -1 */
+int64_t orc_png_encode(const uint8_t* rgb8, int w, int h, uint8_t* out, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
