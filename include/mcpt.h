@@ -1,0 +1,144 @@
+/*
+ * mcpt.h -- C ABI of libmcpt.so, the MI355X-native (gfx950 / HIP) replacement for the hot path of
+ * Arieys/MonteCarloPathTracing:  render_scene -> generateImg -> ray_intersect/bvh_intersect -> shade.
+ *
+ * The reference has no FFI or plugin interface; its boundary is three free C++ functions.  Each entry
+ * point below names the reference function it replaces (paths relative to the reference checkout):
+ *
+ *   mcpt_render_scene      <->  bool render_scene(std::string path, std::string filename, int N)   MTPC/MTPC.cpp:35-68
+ *   mcpt_scene_load        <->  scene_data::read_scene + sort(compare) + BVH::BVH                 MTPC/MTPC.cpp:38-45,
+ *                                                     MTPC/sceneManagement.cpp:264-274, MTPC/BVH.cpp:37-85
+ *   mcpt_render[_device]   <->  void generateImg(scene_data&, BVH&, image&, int)                  MTPC/pathTracing.cpp:274-331
+ *   mcpt_trace_closest[_device] <-> bool ray_intersect(Ray, scene_data&, BVH&, intersection&)      MTPC/pathTracing.cpp:382-390
+ *   mcpt_quantize_rgb8 + mcpt_write_png <-> imshow(double*, W, H, filename, N) + svpng()           MTPC/MTPC.cpp:10-33, MTPC/svpng.inc:77
+ *
+ * Plain pointers and sizes only; the caller owns every buffer, the library owns the opaque handles.
+ * All compute entry points run hand-written HIP kernels on an MI355X; there is NO CPU fallback: without a
+ * HIP device they return MCPT_ERR_NO_DEVICE.  Functions return 0 on success or a negative MCPT_ERR_* code;
+ * mcpt_last_error() gives the message for the calling thread.
+ *
+ * Semantics are the reference's (fp64 arithmetic in the reference's operation order, no FMA contraction)
+ * with the documented seams D1..D8 of DESIGN.md (counter-based RNG instead of time(NULL) engines, stable
+ * Morton sort, serial sample accumulation, CRLF stripping, no virtual-child aliasing, depth cap, texture
+ * clamp, Ns/Ni defaults).
+ */
+#ifndef MCPT_H
+#define MCPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCPT_VERSION 100
+
+#define MCPT_OK             0
+#define MCPT_ERR_IO        -1   /* a scene/texture/output file could not be opened */
+#define MCPT_ERR_PARSE     -2   /* malformed scene (face before usemtl, index out of range, light without material ...) */
+#define MCPT_ERR_ARG       -3   /* bad argument */
+#define MCPT_ERR_NO_DEVICE -4   /* no HIP device / ordinal out of range */
+#define MCPT_ERR_HIP       -5   /* a HIP runtime call failed */
+#define MCPT_ERR_NOMEM     -6
+
+#define MCPT_MAX_DEPTH 64       /* shade() recursion cap (D6) */
+
+typedef struct mcpt_scene  mcpt_scene;    /* host: scene_data + Morton-sorted faces + implicit BVH */
+typedef struct mcpt_device mcpt_device;   /* one GPU's resident copy of a scene (SoA/record arrays in HBM) */
+
+/* MTPC/BVH.h:29 (t, Nv, Nr, Nc, Lc, Lv, Level) */
+typedef struct { int32_t t, Lc, Lv, Nc, Nv, Nr, Level; } mcpt_bvh_info;
+
+typedef struct {
+    int32_t num_faces, num_materials, num_lights, width, height;
+    double eye[3], look_at[3], up[3], fovy;          /* MTPC/sceneManagement.h:150-156 */
+    mcpt_bvh_info bvh;
+} mcpt_scene_info;
+
+typedef struct {
+    uint64_t rays_primary, rays_shadow, rays_bounce; /* closest-hit queries actually traced */
+    uint64_t node_visits, tri_tests;                 /* box tests / triangle tests executed */
+    uint64_t shade_calls, samples;
+    double   ms_trace, ms_total;                     /* device time of the dominant kernel / whole call (HIP events) */
+    int32_t  launches;                               /* launches of the dominant kernel */
+    int32_t  max_depth;
+} mcpt_stats;
+
+typedef struct {
+    int32_t  spp;            /* N_ray_per_pixel */
+    uint64_t seed;           /* RNG seam key (D1) */
+    /* pixel ownership: the frame is cut into tile_w x tile_h tiles numbered row-major; this call renders
+     * tiles with (tile % world) == rank.  world<=1 renders everything.  tile_w/h <= 0 -> 32 x 8. */
+    int32_t  rank, world, tile_w, tile_h;
+    int32_t  flags;          /* MCPT_RENDER_* */
+} mcpt_render_params;
+
+#define MCPT_RENDER_DEFAULT      0
+#define MCPT_RENDER_RETRACE_PRIMARY 1   /* re-trace the (identical) primary ray for every sample like the reference does */
+
+/* ---- general ---- */
+int         mcpt_version(void);
+const char* mcpt_last_error(void);
+int         mcpt_device_count(void);                        /* number of HIP devices (0 without a GPU) */
+
+/* ---- scene (host) ---- */
+/* Reads <path><filename>.obj/.mtl/.camera exactly like read_scene; textures named by map_Kd are looked up
+ * relative to <path> first, then the cwd (reference: cwd only). */
+int  mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out);
+void mcpt_scene_free(mcpt_scene*);
+int  mcpt_scene_set_resolution(mcpt_scene*, int32_t width, int32_t height);   /* overrides .camera width/height */
+int  mcpt_scene_get_info(const mcpt_scene*, mcpt_scene_info* out);
+/* faces in .obj order: 27 doubles each = v1 v2 v3 vn1 vn2 vn3 (xyz) vt1 vt2 vt3 (uv) norm; any pointer may be NULL */
+int  mcpt_scene_get_faces(const mcpt_scene*, double* geom27, int32_t* material, uint32_t* morton);
+int  mcpt_scene_get_leaf_order(const mcpt_scene*, int32_t* leaf_to_face);     /* sorted (leaf) index -> .obj index */
+/* Nr nodes in the reference's compact level order; box6 = max_x,max_y,max_z,min_x,min_y,min_z (sceneManagement.h:165-171) */
+int  mcpt_scene_get_bvh_nodes(const mcpt_scene*, double* box6, int32_t* level, int32_t* leaf_face);
+int  mcpt_scene_find_index(const mcpt_scene*, int32_t i, int32_t l);          /* BVH::findIndex, MTPC/BVH.cpp:99-104 */
+/* rec8 = kd xyz, ks xyz, Ns, Ni; flags4 = has_map, map_width, map_height, light index or -1 */
+int  mcpt_scene_get_material(const mcpt_scene*, int32_t m, char name[64], double rec8[8], int32_t flags4[4]);
+int  mcpt_scene_get_light(const mcpt_scene*, int32_t i, char name[64], double radiance[3], int32_t* material, double* total_area);
+uint32_t mcpt_morton_code(float x, float y, float z);                         /* getMortonCode, MTPC/morton code.cpp:22-32 */
+
+/* ---- device ---- */
+int  mcpt_device_create(const mcpt_scene*, int32_t device_ordinal, mcpt_device** out);
+void mcpt_device_free(mcpt_device*);
+
+/* ---- closest hit (ray_intersect) ---- */
+/* rays: n x 6 doubles (origin xyz, direction xyz).  face[n] = .obj face index or -1, t[n], p[n*3], pn[n*3];
+ * any output may be NULL.  Host-pointer form stages through HBM; the _device form takes device pointers and a
+ * hipStream_t (NULL = default stream) and is asynchronous. */
+int  mcpt_trace_closest(mcpt_device*, const double* rays, int64_t n, int32_t* face, double* t, double* p, double* pn, mcpt_stats* stats);
+int  mcpt_trace_closest_device(mcpt_device*, const double* d_rays, int64_t n, int32_t* d_face, double* d_t, double* d_p, double* d_pn, void* stream);
+
+/* ---- integrator (generateImg) ---- */
+/* img: H*W*3 doubles, index (row*W + col)*3 + c (image::getIndex, sceneManagement.h:232-234).  Pixels this
+ * rank does not own are left untouched.  stats may be NULL. */
+int  mcpt_render(mcpt_device*, const mcpt_render_params*, double* img, mcpt_stats* stats);
+int  mcpt_render_device(mcpt_device*, const mcpt_render_params*, double* d_img, mcpt_stats* stats, void* stream);
+/* radiance of single camera samples: pix[n] = row*W+col, k[n] = sample index -> rgb[n*3] (test seam, host pointers) */
+int  mcpt_sample_radiance(mcpt_device*, uint64_t seed, const int32_t* pix, const int32_t* k, int64_t n, double* rgb);
+/* number of pixels owned by (rank, world) under the tile partition, and their indices (row*W+col, ascending) */
+int64_t mcpt_owned_pixels(const mcpt_scene*, const mcpt_render_params*, int32_t* pixels /* may be NULL */);
+
+/* ---- output (imshow + svpng) ---- */
+int  mcpt_quantize_rgb8(const double* img, int64_t n, uint8_t* rgb8);        /* (unsigned char)clamp(v*255,0,255) */
+int  mcpt_write_png(const char* file, const uint8_t* rgb8, int32_t width, int32_t height);
+int64_t mcpt_png_encode(const uint8_t* rgb8, int32_t width, int32_t height, uint8_t* out, int64_t cap);
+
+/* ---- whole program (render_scene) ---- */
+/* Reads <path><filename>.*, renders with N samples per pixel on GPU 0 and writes
+ * "../result/<filename>-SPP<N>.png" relative to the cwd, like the reference. */
+int  mcpt_render_scene(const char* path, const char* filename, int32_t spp);
+typedef struct {
+    uint64_t seed;
+    int32_t  device;            /* HIP ordinal */
+    int32_t  width, height;     /* >0 overrides the .camera resolution */
+    int32_t  quiet;             /* suppress the reference-style progress prints */
+    const char* output_prefix;  /* NULL -> "../result/<filename>"; file = <prefix>-SPP<N>.png */
+} mcpt_render_scene_options;
+int  mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options*, mcpt_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCPT_H */

@@ -1,0 +1,125 @@
+"""Loader of the in-tree libmcpt.so (host C++ + HIP kernels for gfx950).  No fallback: if the shared library is
+missing or has no device to run on, the calls raise."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmcpt.so")
+
+
+class McptError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmcpt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("t", "Lc", "Lv", "Nc", "Nv", "Nr", "Level")]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("num_faces", C.c_int32), ("num_materials", C.c_int32), ("num_lights", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32),
+                ("eye", C.c_double * 3), ("look_at", C.c_double * 3), ("up", C.c_double * 3), ("fovy", C.c_double),
+                ("bvh", BvhInfo)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("shade_calls", C.c_uint64),
+                ("samples", C.c_uint64), ("ms_trace", C.c_double), ("ms_total", C.c_double),
+                ("launches", C.c_int32), ("max_depth", C.c_int32)]
+
+    @property
+    def rays(self):
+        return self.rays_primary + self.rays_shadow + self.rays_bounce
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["rays"] = self.rays
+        return d
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32),
+                ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("flags", C.c_int32)]
+
+
+class RenderSceneOptions(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("quiet", C.c_int32), ("output_prefix", C.c_char_p)]
+
+
+# every symbol include/mcpt.h declares
+EXPORTS = [
+    "mcpt_version", "mcpt_last_error", "mcpt_device_count",
+    "mcpt_scene_load", "mcpt_scene_free", "mcpt_scene_set_resolution", "mcpt_scene_get_info", "mcpt_scene_get_faces",
+    "mcpt_scene_get_leaf_order", "mcpt_scene_get_bvh_nodes", "mcpt_scene_find_index", "mcpt_scene_get_material",
+    "mcpt_scene_get_light", "mcpt_morton_code",
+    "mcpt_device_create", "mcpt_device_free",
+    "mcpt_trace_closest", "mcpt_trace_closest_device",
+    "mcpt_render", "mcpt_render_device", "mcpt_sample_radiance", "mcpt_owned_pixels",
+    "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode",
+    "mcpt_render_scene", "mcpt_render_scene_ex",
+]
+
+
+def build(verbose=False):
+    """Compile libmcpt.so in-tree (hipcc --offload-arch=gfx950; works without a GPU)."""
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "all"], stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libmcpt.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C montecarlopathtracing_amd/csrc` (needs hipcc)")
+    L = C.CDLL(LIB_PATH)
+    P, D, I32, U8 = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.mcpt_version.restype = C.c_int
+    L.mcpt_last_error.restype = C.c_char_p
+    L.mcpt_device_count.restype = C.c_int
+    L.mcpt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(P)]
+    L.mcpt_scene_free.argtypes = [P]
+    L.mcpt_scene_free.restype = None
+    L.mcpt_scene_set_resolution.argtypes = [P, C.c_int32, C.c_int32]
+    L.mcpt_scene_get_info.argtypes = [P, C.POINTER(SceneInfo)]
+    L.mcpt_scene_get_faces.argtypes = [P, D, I32, C.POINTER(C.c_uint32)]
+    L.mcpt_scene_get_leaf_order.argtypes = [P, I32]
+    L.mcpt_scene_get_bvh_nodes.argtypes = [P, D, I32, I32]
+    L.mcpt_scene_find_index.argtypes = [P, C.c_int32, C.c_int32]
+    L.mcpt_scene_get_material.argtypes = [P, C.c_int32, C.c_char_p, D, I32]
+    L.mcpt_scene_get_light.argtypes = [P, C.c_int32, C.c_char_p, D, I32, D]
+    L.mcpt_morton_code.restype = C.c_uint32
+    L.mcpt_morton_code.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.mcpt_device_create.argtypes = [P, C.c_int32, C.POINTER(P)]
+    L.mcpt_device_free.argtypes = [P]
+    L.mcpt_device_free.restype = None
+    L.mcpt_trace_closest.argtypes = [P, D, C.c_int64, I32, D, D, D, C.POINTER(Stats)]
+    L.mcpt_trace_closest_device.argtypes = [P, P, C.c_int64, P, P, P, P, P]
+    L.mcpt_render.argtypes = [P, C.POINTER(RenderParams), D, C.POINTER(Stats)]
+    L.mcpt_render_device.argtypes = [P, C.POINTER(RenderParams), P, C.POINTER(Stats), P]
+    L.mcpt_sample_radiance.argtypes = [P, C.c_uint64, I32, I32, C.c_int64, D]
+    L.mcpt_owned_pixels.restype = C.c_int64
+    L.mcpt_owned_pixels.argtypes = [P, C.POINTER(RenderParams), I32]
+    L.mcpt_quantize_rgb8.argtypes = [D, C.c_int64, U8]
+    L.mcpt_write_png.argtypes = [C.c_char_p, U8, C.c_int32, C.c_int32]
+    L.mcpt_png_encode.restype = C.c_int64
+    L.mcpt_png_encode.argtypes = [U8, C.c_int32, C.c_int32, U8, C.c_int64]
+    L.mcpt_render_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+    L.mcpt_render_scene_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(RenderSceneOptions), C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise McptError(rc, lib().mcpt_last_error().decode(errors="replace"))

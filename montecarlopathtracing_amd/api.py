@@ -1,0 +1,186 @@
+"""Python face of libmcpt's C ABI, named after the reference's own functions and types
+(render_scene / scene_data / BVH / ray_intersect / generateImg / imshow)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import McptError, RenderParams, RenderSceneOptions, SceneInfo, Stats, check, lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def device_count():
+    return lib().mcpt_device_count()
+
+
+class Scene:
+    """scene_data::read_scene + Morton sort + BVH::BVH (MTPC/MTPC.cpp:38-45)."""
+
+    def __init__(self, path, filename, width=None, height=None):
+        self._h = C.c_void_p()
+        check(lib().mcpt_scene_load(path.encode(), filename.encode(), C.byref(self._h)))
+        if width is not None:
+            self.set_resolution(width, height)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mcpt_scene_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_resolution(self, width, height):
+        check(lib().mcpt_scene_set_resolution(self._h, width, height))
+
+    @property
+    def info(self):
+        i = SceneInfo()
+        check(lib().mcpt_scene_get_info(self._h, C.byref(i)))
+        return i
+
+    @property
+    def width(self):
+        return self.info.width
+
+    @property
+    def height(self):
+        return self.info.height
+
+    def faces(self):
+        n = self.info.num_faces
+        g = np.zeros((n, 27))
+        m = np.zeros(n, dtype=np.int32)
+        k = np.zeros(n, dtype=np.uint32)
+        check(lib().mcpt_scene_get_faces(self._h, _p(g, C.c_double), _p(m, C.c_int32), _p(k, C.c_uint32)))
+        return g, m, k
+
+    def leaf_order(self):
+        o = np.zeros(self.info.num_faces, dtype=np.int32)
+        check(lib().mcpt_scene_get_leaf_order(self._h, _p(o, C.c_int32)))
+        return o
+
+    def bvh_nodes(self):
+        nr = self.info.bvh.Nr
+        box = np.zeros((nr, 6))
+        lvl = np.zeros(nr, dtype=np.int32)
+        leaf = np.zeros(nr, dtype=np.int32)
+        check(lib().mcpt_scene_get_bvh_nodes(self._h, _p(box, C.c_double), _p(lvl, C.c_int32), _p(leaf, C.c_int32)))
+        return box, lvl, leaf
+
+    def find_index(self, i, l):
+        return lib().mcpt_scene_find_index(self._h, i, l)
+
+    def material(self, m):
+        name = C.create_string_buffer(64)
+        rec = np.zeros(8)
+        fl = np.zeros(4, dtype=np.int32)
+        check(lib().mcpt_scene_get_material(self._h, m, name, _p(rec, C.c_double), _p(fl, C.c_int32)))
+        return name.value.decode(), rec, fl
+
+    def light(self, i):
+        name = C.create_string_buffer(64)
+        rad = np.zeros(3)
+        m = np.zeros(1, dtype=np.int32)
+        a = np.zeros(1)
+        check(lib().mcpt_scene_get_light(self._h, i, name, _p(rad, C.c_double), _p(m, C.c_int32), _p(a, C.c_double)))
+        return name.value.decode(), rad, int(m[0]), float(a[0])
+
+    def owned_pixels(self, rank=0, world=1, tile_w=0, tile_h=0):
+        rp = RenderParams(1, 0, rank, world, tile_w, tile_h, 0)
+        n = lib().mcpt_owned_pixels(self._h, C.byref(rp), None)
+        if n < 0:
+            check(int(n))
+        out = np.zeros(n, dtype=np.int32)
+        lib().mcpt_owned_pixels(self._h, C.byref(rp), _p(out, C.c_int32))
+        return out
+
+
+class Device:
+    """One MI355X holding a resident copy of a Scene."""
+
+    def __init__(self, scene, ordinal=0):
+        self.scene = scene
+        self._h = C.c_void_p()
+        check(lib().mcpt_device_create(scene._h, ordinal, C.byref(self._h)))
+        i = scene.info
+        self.width, self.height = i.width, i.height
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mcpt_device_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def ray_intersect(self, rays, stats=None):
+        """Batch of ray_intersect (MTPC/pathTracing.cpp:382): rays [n,6] -> face (.obj index or -1), t, p, pn."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = rays.shape[0]
+        face = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n)
+        p = np.zeros((n, 3))
+        pn = np.zeros((n, 3))
+        check(lib().mcpt_trace_closest(self._h, _p(rays, C.c_double), n, _p(face, C.c_int32), _p(t, C.c_double),
+                                       _p(p, C.c_double), _p(pn, C.c_double), C.byref(stats) if stats is not None else None))
+        return face, t, p, pn
+
+    def generateImg(self, spp, seed=0, rank=0, world=1, tile_w=0, tile_h=0, flags=0, stats=None, img=None):
+        """generateImg (MTPC/pathTracing.cpp:274): returns image::img as [H,W,3] float64."""
+        if img is None:
+            img = np.zeros((self.height, self.width, 3))
+        rp = RenderParams(spp, seed, rank, world, tile_w, tile_h, flags)
+        check(lib().mcpt_render(self._h, C.byref(rp), _p(img, C.c_double), C.byref(stats) if stats is not None else None))
+        return img
+
+    def render_device(self, d_img_ptr, spp, seed=0, rank=0, world=1, tile_w=0, tile_h=0, flags=0, stats=None, stream=None):
+        """Same, into a caller-owned device buffer (e.g. a torch tensor's data_ptr()) on `stream`."""
+        rp = RenderParams(spp, seed, rank, world, tile_w, tile_h, flags)
+        check(lib().mcpt_render_device(self._h, C.byref(rp), C.c_void_p(d_img_ptr), C.byref(stats) if stats is not None else None,
+                                       C.c_void_p(stream) if stream else None))
+
+    def sample_radiance(self, seed, pix, k):
+        pix = np.ascontiguousarray(pix, dtype=np.int32)
+        k = np.ascontiguousarray(k, dtype=np.int32)
+        rgb = np.zeros((pix.shape[0], 3))
+        check(lib().mcpt_sample_radiance(self._h, seed, _p(pix, C.c_int32), _p(k, C.c_int32), pix.shape[0], _p(rgb, C.c_double)))
+        return rgb
+
+
+def imshow_rgb8(img):
+    """The 8-bit conversion of imshow (MTPC/MTPC.cpp:22-30)."""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    out = np.zeros(img.shape, dtype=np.uint8)
+    check(lib().mcpt_quantize_rgb8(_p(img, C.c_double), img.size, _p(out, C.c_uint8)))
+    return out
+
+
+def png_bytes(rgb8):
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    cap = 128 + h * (w * 3 + 6)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().mcpt_png_encode(_p(rgb8, C.c_uint8), w, h, _p(out, C.c_uint8), cap)
+    if n < 0:
+        check(int(n))
+    return out[:n].tobytes()
+
+
+def write_png(file, rgb8):
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    check(lib().mcpt_write_png(file.encode(), _p(rgb8, C.c_uint8), w, h))
+
+
+def morton_code(x, y, z):
+    return lib().mcpt_morton_code(x, y, z)
+
+
+def render_scene(path, filename, N_ray_per_pixel, seed=0, device=0, width=0, height=0, quiet=True, output_prefix=None, stats=None):
+    """render_scene(path, filename, N) of MTPC/MTPC.cpp:35; writes <prefix>-SPP<N>.png (default ../result/<filename>)."""
+    o = RenderSceneOptions(seed, device, width, height, int(quiet), output_prefix.encode() if output_prefix else None)
+    check(lib().mcpt_render_scene_ex(path.encode(), filename.encode(), N_ray_per_pixel, C.byref(o),
+                                     C.byref(stats) if stats is not None else None))
+    return True

@@ -1,0 +1,607 @@
+// C ABI of libmcpt.so (include/mcpt.h): host scene handles, device residency, and the launch sequences that
+// stand in for ray_intersect / generateImg / imshow / render_scene of the reference.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "scene.hpp"
+
+using namespace mcpt;
+
+namespace {
+thread_local std::string g_error;
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(MCPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+template <class T>
+int upload(const std::vector<T>& h, T** d)
+{
+    *d = nullptr;
+    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(d), bytes));
+    if (!h.empty()) HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MCPT_OK;
+}
+}  // namespace
+
+struct mcpt_scene {
+    Scene s;
+};
+
+struct mcpt_device {
+    int ordinal = 0;
+    DScene ds{};
+    hipStream_t stream = nullptr;          // library stream for the host-pointer entry points
+    // scene arrays
+    DNode* nodes = nullptr; DTri* tris = nullptr; DTriShade* shade = nullptr; DMaterial* materials = nullptr;
+    DLight* lights = nullptr; DLightTri* light_tris = nullptr; double* light_cdf = nullptr; uint8_t* texels = nullptr;
+    // frame state
+    int width = 0, height = 0;
+    double* dirs = nullptr;                // W*H*3 primary directions
+    bool dirs_ready = false;
+    DCounters* ctr = nullptr;
+    // render workspace
+    int32_t* pixels = nullptr; int64_t n_pixels = 0; int part_key[4] = {-1, -1, -1, -1};
+    PrimaryHit* hits = nullptr; int64_t hits_cap = 0;
+    double* rad = nullptr; size_t rad_cap = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t sample_budget_bytes = size_t(4) << 30;   // radiance staging buffer (pixels x spp x 24 B per chunk)
+    Scene const* host = nullptr;           // not owned; used for the partition only (copied fields below)
+    int part_w = 0, part_h = 0;
+};
+
+extern "C" {
+
+int mcpt_version(void) { return MCPT_VERSION; }
+const char* mcpt_last_error(void) { return g_error.c_str(); }
+
+int mcpt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ scene
+int mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out)
+{
+    if (!path || !filename || !out) return fail(MCPT_ERR_ARG, "null argument");
+    *out = nullptr;
+    std::unique_ptr<mcpt_scene> h(new mcpt_scene);
+    std::string err;
+    int rc = load_scene_files(path, filename, h->s, err);
+    if (rc) return fail(rc, err);
+    rc = build_accel(h->s, err);
+    if (rc) return fail(rc, err);
+    *out = h.release();
+    return MCPT_OK;
+}
+void mcpt_scene_free(mcpt_scene* s) { delete s; }
+
+int mcpt_scene_set_resolution(mcpt_scene* s, int32_t w, int32_t h)
+{
+    if (!s || w <= 0 || h <= 0) return fail(MCPT_ERR_ARG, "bad resolution");
+    s->s.width = w; s->s.height = h;
+    return MCPT_OK;
+}
+
+int mcpt_scene_get_info(const mcpt_scene* h, mcpt_scene_info* o)
+{
+    if (!h || !o) return fail(MCPT_ERR_ARG, "null argument");
+    const Scene& s = h->s;
+    o->num_faces = int32_t(s.faces.size()); o->num_materials = int32_t(s.materials.size()); o->num_lights = int32_t(s.lights.size());
+    o->width = s.width; o->height = s.height;
+    o->eye[0] = s.eye.x; o->eye[1] = s.eye.y; o->eye[2] = s.eye.z;
+    o->look_at[0] = s.look_at.x; o->look_at[1] = s.look_at.y; o->look_at[2] = s.look_at.z;
+    o->up[0] = s.up.x; o->up[1] = s.up.y; o->up[2] = s.up.z;
+    o->fovy = s.fovy; o->bvh = s.bi;
+    return MCPT_OK;
+}
+
+int mcpt_scene_get_faces(const mcpt_scene* h, double* g, int32_t* material, uint32_t* morton)
+{
+    if (!h) return fail(MCPT_ERR_ARG, "null scene");
+    const Scene& s = h->s;
+    for (size_t i = 0; i < s.faces.size(); i++) {
+        const FaceRec& f = s.faces[i];
+        if (g) {
+            double* o = g + i * 27;
+            for (int c = 0; c < 3; c++) { o[c * 3] = f.v[c].x; o[c * 3 + 1] = f.v[c].y; o[c * 3 + 2] = f.v[c].z; }
+            for (int c = 0; c < 3; c++) { o[9 + c * 3] = f.vn[c].x; o[9 + c * 3 + 1] = f.vn[c].y; o[9 + c * 3 + 2] = f.vn[c].z; }
+            for (int c = 0; c < 3; c++) { o[18 + c * 2] = f.vt[c][0]; o[18 + c * 2 + 1] = f.vt[c][1]; }
+            o[24] = f.nrm.x; o[25] = f.nrm.y; o[26] = f.nrm.z;
+        }
+        if (material) material[i] = f.material;
+        if (morton) morton[i] = f.morton;
+    }
+    return MCPT_OK;
+}
+
+int mcpt_scene_get_leaf_order(const mcpt_scene* h, int32_t* o)
+{
+    if (!h || !o) return fail(MCPT_ERR_ARG, "null argument");
+    std::copy(h->s.order.begin(), h->s.order.end(), o);
+    return MCPT_OK;
+}
+
+int mcpt_scene_get_bvh_nodes(const mcpt_scene* h, double* box6, int32_t* level, int32_t* leaf_face)
+{
+    if (!h) return fail(MCPT_ERR_ARG, "null scene");
+    const Scene& s = h->s;
+    for (int i = 0; i < s.bi.Nr; i++) {
+        const NodeBox& b = s.nodes[i];
+        if (box6) { double* o = box6 + size_t(i) * 6; o[0] = b.max_x; o[1] = b.max_y; o[2] = b.max_z; o[3] = b.min_x; o[4] = b.min_y; o[5] = b.min_z; }
+        if (level) level[i] = s.node_level[i];
+        if (leaf_face) leaf_face[i] = s.node_leaf[i] >= 0 ? s.order[s.node_leaf[i]] : -1;
+    }
+    return MCPT_OK;
+}
+
+int mcpt_scene_find_index(const mcpt_scene* h, int32_t i, int32_t l) { return h ? find_index(h->s.bi, i, l) : -1; }
+
+int mcpt_scene_get_material(const mcpt_scene* h, int32_t m, char name[64], double r[8], int32_t fl[4])
+{
+    if (!h || m < 0 || m >= int(h->s.materials.size())) return fail(MCPT_ERR_ARG, "material index");
+    const MaterialRec& mt = h->s.materials[m];
+    if (name) { std::memset(name, 0, 64); std::strncpy(name, mt.name.c_str(), 63); }
+    if (r) { r[0] = mt.kd.x; r[1] = mt.kd.y; r[2] = mt.kd.z; r[3] = mt.ks.x; r[4] = mt.ks.y; r[5] = mt.ks.z; r[6] = mt.Ns; r[7] = mt.Ni; }
+    if (fl) { fl[0] = mt.has_map; fl[1] = mt.map_w; fl[2] = mt.map_h; fl[3] = mt.light; }
+    return MCPT_OK;
+}
+
+int mcpt_scene_get_light(const mcpt_scene* h, int32_t i, char name[64], double rad[3], int32_t* material, double* area)
+{
+    if (!h || i < 0 || i >= int(h->s.lights.size())) return fail(MCPT_ERR_ARG, "light index");
+    const LightRec& l = h->s.lights[i];
+    if (name) { std::memset(name, 0, 64); std::strncpy(name, l.name.c_str(), 63); }
+    if (rad) { rad[0] = l.radiance.x; rad[1] = l.radiance.y; rad[2] = l.radiance.z; }
+    if (material) *material = l.material;
+    if (area) *area = l.total_area;
+    return MCPT_OK;
+}
+
+uint32_t mcpt_morton_code(float x, float y, float z) { return morton_code(x, y, z); }
+
+// ------------------------------------------------------------------------------------------------ partition
+static void tile_shape(const mcpt_render_params* p, int& tw, int& th, int& rank, int& world)
+{
+    tw = (p && p->tile_w > 0) ? p->tile_w : 32;
+    th = (p && p->tile_h > 0) ? p->tile_h : 8;
+    world = (p && p->world > 1) ? p->world : 1;
+    rank = (p && world > 1) ? p->rank : 0;
+}
+
+static void owned_pixel_list(int W, int H, int tw, int th, int rank, int world, std::vector<int32_t>& out)
+{
+    out.clear();
+    const int tiles_x = (W + tw - 1) / tw;
+    for (int y = 0; y < H; y++) {
+        const int ty = y / th;
+        for (int x = 0; x < W; x++) {
+            const int tile = ty * tiles_x + x / tw;
+            if (tile % world == rank) out.push_back(y * W + x);
+        }
+    }
+}
+
+int64_t mcpt_owned_pixels(const mcpt_scene* h, const mcpt_render_params* p, int32_t* pixels)
+{
+    if (!h) return fail(MCPT_ERR_ARG, "null scene");
+    int tw, th, rank, world;
+    tile_shape(p, tw, th, rank, world);
+    if (rank < 0 || rank >= world) return fail(MCPT_ERR_ARG, "rank outside world");
+    std::vector<int32_t> v;
+    owned_pixel_list(h->s.width, h->s.height, tw, th, rank, world, v);
+    if (pixels) std::copy(v.begin(), v.end(), pixels);
+    return int64_t(v.size());
+}
+
+// ------------------------------------------------------------------------------------------------ device
+void mcpt_device_free(mcpt_device* d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->ordinal);
+    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels,
+                    d->dirs, d->ctr, d->pixels, d->hits, d->rad};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
+{
+    if (!h || !out) return fail(MCPT_ERR_ARG, "null argument");
+    *out = nullptr;
+    int ndev = mcpt_device_count();
+    if (ndev <= 0) return fail(MCPT_ERR_NO_DEVICE, "no HIP device available (libmcpt has no CPU fallback)");
+    if (ordinal < 0 || ordinal >= ndev) return fail(MCPT_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(ordinal));
+    const Scene& s = h->s;
+    std::unique_ptr<mcpt_device, void (*)(mcpt_device*)> d(new mcpt_device, mcpt_device_free);
+    d->ordinal = ordinal;
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
+
+    const int t = s.bi.t;
+    std::vector<DNode> nodes(s.bi.Nr);
+    for (int i = 0; i < s.bi.Nr; i++) {
+        const NodeBox& b = s.nodes[i];
+        DNode n{};
+        n.mn[0] = b.min_x; n.mn[1] = b.min_y; n.mn[2] = b.min_z; n.mx[0] = b.max_x; n.mx[1] = b.max_y; n.mx[2] = b.max_z;
+        nodes[i] = n;
+    }
+    std::vector<DTri> tris(t);
+    std::vector<DTriShade> shade(t);
+    for (int k = 0; k < t; k++) {
+        const FaceRec& f = s.faces[s.order[k]];
+        DTri q{};
+        DTriShade a{};
+        const Vec3* vs[3] = {&f.v[0], &f.v[1], &f.v[2]};
+        double* dst[3] = {q.v1, q.v2, q.v3};
+        for (int c = 0; c < 3; c++) { dst[c][0] = vs[c]->x; dst[c][1] = vs[c]->y; dst[c][2] = vs[c]->z; }
+        q.n[0] = f.nrm.x; q.n[1] = f.nrm.y; q.n[2] = f.nrm.z;
+        q.material = f.material; q.face = s.order[k];
+        double* nd[3] = {a.vn1, a.vn2, a.vn3};
+        for (int c = 0; c < 3; c++) { nd[c][0] = f.vn[c].x; nd[c][1] = f.vn[c].y; nd[c][2] = f.vn[c].z; }
+        a.vt1[0] = f.vt[0][0]; a.vt1[1] = f.vt[0][1]; a.vt2[0] = f.vt[1][0]; a.vt2[1] = f.vt[1][1]; a.vt3[0] = f.vt[2][0]; a.vt3[1] = f.vt[2][1];
+        tris[k] = q; shade[k] = a;
+    }
+    std::vector<uint8_t> texels;
+    std::vector<DMaterial> mats(s.materials.size());
+    for (size_t i = 0; i < s.materials.size(); i++) {
+        const MaterialRec& m = s.materials[i];
+        DMaterial dm{};
+        dm.kd[0] = m.kd.x; dm.kd[1] = m.kd.y; dm.kd[2] = m.kd.z; dm.ks[0] = m.ks.x; dm.ks[1] = m.ks.y; dm.ks[2] = m.ks.z;
+        dm.Ns = m.Ns; dm.Ni = m.Ni; dm.has_map = m.has_map; dm.map_w = m.map_w; dm.map_h = m.map_h; dm.light = m.light;
+        dm.tex_offset = int64_t(texels.size());
+        texels.insert(texels.end(), m.bgr.begin(), m.bgr.end());
+        mats[i] = dm;
+    }
+    std::vector<DLight> lights(s.lights.size());
+    std::vector<DLightTri> ltris;
+    std::vector<double> lcdf;
+    for (size_t i = 0; i < s.lights.size(); i++) {
+        const LightRec& l = s.lights[i];
+        const MaterialRec& m = s.materials[l.material];
+        DLight dl{};
+        dl.radiance[0] = l.radiance.x; dl.radiance[1] = l.radiance.y; dl.radiance[2] = l.radiance.z;
+        dl.total_area = l.total_area; dl.material = l.material; dl.ntri = int32_t(m.faces.size());
+        dl.first = int32_t(ltris.size()); dl.cdf_sorted = l.cdf_sorted ? 1 : 0;
+        for (size_t j = 0; j < m.faces.size(); j++) {
+            const FaceRec& f = s.faces[m.faces[j]];
+            DLightTri q{};
+            double* pv[3] = {q.v1, q.v2, q.v3};
+            double* pn[3] = {q.vn1, q.vn2, q.vn3};
+            for (int c = 0; c < 3; c++) {
+                pv[c][0] = f.v[c].x; pv[c][1] = f.v[c].y; pv[c][2] = f.v[c].z;
+                pn[c][0] = f.vn[c].x; pn[c][1] = f.vn[c].y; pn[c][2] = f.vn[c].z;
+            }
+            ltris.push_back(q);
+            lcdf.push_back(l.cdf[j]);
+        }
+        lights[i] = dl;
+    }
+    int rc;
+    if ((rc = upload(nodes, &d->nodes)) || (rc = upload(tris, &d->tris)) || (rc = upload(shade, &d->shade)) ||
+        (rc = upload(mats, &d->materials)) || (rc = upload(lights, &d->lights)) || (rc = upload(ltris, &d->light_tris)) ||
+        (rc = upload(lcdf, &d->light_cdf)) || (rc = upload(texels, &d->texels)))
+        return rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->ctr), sizeof(DCounters)));
+    HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
+
+    DScene& S = d->ds;
+    S.nodes = d->nodes; S.tris = d->tris; S.shade = d->shade; S.materials = d->materials; S.lights = d->lights;
+    S.light_tris = d->light_tris; S.light_cdf = d->light_cdf; S.texels = d->texels;
+    S.t = t; S.Lv = s.bi.Lv; S.Level = s.bi.Level; S.Nr = s.bi.Nr;
+    S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
+    S.area0 = s.area0;
+    const CameraFrame cf = camera_frame(s);
+    S.cam.eye[0] = cf.eye.x; S.cam.eye[1] = cf.eye.y; S.cam.eye[2] = cf.eye.z;
+    S.cam.start_point[0] = cf.start_point.x; S.cam.start_point[1] = cf.start_point.y; S.cam.start_point[2] = cf.start_point.z;
+    S.cam.pdx[0] = cf.screen_pdx.x; S.cam.pdx[1] = cf.screen_pdx.y; S.cam.pdx[2] = cf.screen_pdx.z;
+    S.cam.pdy[0] = cf.screen_pdy.x; S.cam.pdy[1] = cf.screen_pdy.y; S.cam.pdy[2] = cf.screen_pdy.z;
+    S.cam.width = s.width; S.cam.height = s.height;
+    d->width = s.width; d->height = s.height;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->dirs), size_t(s.width) * s.height * 3 * sizeof(double)));
+    *out = d.release();
+    return MCPT_OK;
+}
+
+static int ensure_dirs(mcpt_device* d, hipStream_t st)
+{
+    if (!d->dirs_ready) {
+        launch_primary_dirs(d->ds.cam, d->dirs, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        d->dirs_ready = true;
+    }
+    return MCPT_OK;
+}
+
+static void counters_to_stats(const DCounters& c, mcpt_stats* s)
+{
+    s->rays_primary = c.rays_primary; s->rays_shadow = c.rays_shadow; s->rays_bounce = c.rays_bounce;
+    s->node_visits = c.node_visits; s->tri_tests = c.tri_tests; s->shade_calls = c.shade_calls; s->samples = c.samples;
+    s->max_depth = int32_t(c.max_depth);
+}
+
+// ------------------------------------------------------------------------------------------------ closest hit
+int mcpt_trace_closest_device(mcpt_device* d, const double* d_rays, int64_t n, int32_t* d_face, double* d_t, double* d_p,
+                              double* d_pn, void* stream)
+{
+    if (!d || (n > 0 && !d_rays) || n < 0) return fail(MCPT_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(d->ordinal));
+    launch_trace_closest(d->ds, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return MCPT_OK;
+}
+
+int mcpt_trace_closest(mcpt_device* d, const double* rays, int64_t n, int32_t* face, double* t, double* p, double* pn, mcpt_stats* stats)
+{
+    if (!d || (n > 0 && !rays) || n < 0) return fail(MCPT_ERR_ARG, "bad argument");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return MCPT_OK;
+    HIP_TRY(hipSetDevice(d->ordinal));
+    double *d_rays = nullptr, *d_t = nullptr, *d_p = nullptr, *d_pn = nullptr;
+    int32_t* d_face = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_rays); (void)hipFree(d_t); (void)hipFree(d_p); (void)hipFree(d_pn); (void)hipFree(d_face); };
+#define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(MCPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rays), size_t(n) * 6 * sizeof(double)));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_face), size_t(n) * sizeof(int32_t)));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_t), size_t(n) * sizeof(double)));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_p), size_t(n) * 3 * sizeof(double)));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_pn), size_t(n) * 3 * sizeof(double)));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_rays, rays, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice, d->stream));
+    TRY_OR_CLEAN(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), d->stream));
+    TRY_OR_CLEAN(hipEventRecord(d->ev[0], d->stream));
+    launch_trace_closest(d->ds, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->stream);
+    TRY_OR_CLEAN(hipGetLastError());
+    TRY_OR_CLEAN(hipEventRecord(d->ev[1], d->stream));
+    if (face) TRY_OR_CLEAN(hipMemcpyAsync(face, d_face, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+    if (t) TRY_OR_CLEAN(hipMemcpyAsync(t, d_t, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    if (p) TRY_OR_CLEAN(hipMemcpyAsync(p, d_p, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    if (pn) TRY_OR_CLEAN(hipMemcpyAsync(pn, d_pn, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    DCounters c{};
+    TRY_OR_CLEAN(hipMemcpyAsync(&c, d->ctr, sizeof c, hipMemcpyDeviceToHost, d->stream));
+    TRY_OR_CLEAN(hipStreamSynchronize(d->stream));
+    if (stats) {
+        counters_to_stats(c, stats);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, d->ev[0], d->ev[1]);
+        stats->ms_trace = ms; stats->ms_total = ms; stats->launches = 1;
+    }
+    cleanup();
+#undef TRY_OR_CLEAN
+    return MCPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ integrator
+static int prepare_partition(mcpt_device* d, const mcpt_render_params* p, hipStream_t st)
+{
+    int tw, th, rank, world;
+    tile_shape(p, tw, th, rank, world);
+    if (rank < 0 || rank >= world) return fail(MCPT_ERR_ARG, "rank outside world");
+    const int key[4] = {tw, th, rank, world};
+    if (std::memcmp(key, d->part_key, sizeof key) == 0 && d->pixels) return MCPT_OK;
+    std::vector<int32_t> v;
+    owned_pixel_list(d->width, d->height, tw, th, rank, world, v);
+    if (d->pixels) { (void)hipFree(d->pixels); d->pixels = nullptr; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->pixels), std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
+    if (!v.empty()) {
+        HIP_TRY(hipMemcpyAsync(d->pixels, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));     // v goes out of scope
+    }
+    d->n_pixels = int64_t(v.size());
+    std::memcpy(d->part_key, key, sizeof key);
+    return MCPT_OK;
+}
+
+int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, void* stream)
+{
+    if (!d || !p || !d_img || p->spp <= 0) return fail(MCPT_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(d->ordinal));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    int rc = ensure_dirs(d, st);
+    if (rc) return rc;
+    rc = prepare_partition(d, p, st);
+    if (rc) return rc;
+    const int64_t npx = d->n_pixels;
+    if (npx == 0) return MCPT_OK;
+    if (d->hits_cap < npx) {
+        if (d->hits) (void)hipFree(d->hits);
+        d->hits = nullptr; d->hits_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->hits), size_t(npx) * sizeof(PrimaryHit)));
+        d->hits_cap = npx;
+    }
+    const int spp = p->spp;
+    const size_t per_pixel = size_t(spp) * 3 * sizeof(double);
+    int64_t chunk = int64_t(std::max<size_t>(d->sample_budget_bytes / per_pixel, 64));
+    chunk = std::min<int64_t>(chunk, npx);
+    // keep n_slots*spp within int range of the kernels' index math (long long there, int slots here)
+    if (d->rad_cap < size_t(chunk) * per_pixel) {
+        if (d->rad) (void)hipFree(d->rad);
+        d->rad = nullptr; d->rad_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->rad), size_t(chunk) * per_pixel));
+        d->rad_cap = size_t(chunk) * per_pixel;
+    }
+    HIP_TRY(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), st));
+    HIP_TRY(hipEventRecord(d->ev[0], st));
+    launch_primary_hits(d->ds, d->dirs, d->pixels, int(npx), d->hits, d->ctr, st);
+    HIP_TRY(hipGetLastError());
+    double ms_trace = 0;
+    int launches = 0;
+    for (int64_t first = 0; first < npx; first += chunk) {
+        const int n_slots = int(std::min<int64_t>(chunk, npx - first));
+        if (stats) HIP_TRY(hipEventRecord(d->ev[2], st));
+        launch_shade_samples(d->ds, p->seed, d->dirs, d->pixels, d->hits, int(first), n_slots, spp, d->rad, d->ctr, st);
+        HIP_TRY(hipGetLastError());
+        if (stats) {
+            HIP_TRY(hipEventRecord(d->ev[3], st));
+            HIP_TRY(hipEventSynchronize(d->ev[3]));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev[2], d->ev[3]));
+            ms_trace += ms;
+        }
+        launches++;
+        launch_fold_samples(d->rad, d->pixels, int(first), n_slots, spp, d_img, st);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(d->ev[1], st));
+    if (stats) {
+        DCounters c{};
+        HIP_TRY(hipMemcpyAsync(&c, d->ctr, sizeof c, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        counters_to_stats(c, stats);
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
+        stats->ms_total = ms; stats->ms_trace = ms_trace; stats->launches = launches;
+    }
+    return MCPT_OK;
+}
+
+int mcpt_render(mcpt_device* d, const mcpt_render_params* p, double* img, mcpt_stats* stats)
+{
+    if (!d || !p || !img) return fail(MCPT_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(d->ordinal));
+    const size_t bytes = size_t(d->width) * d->height * 3 * sizeof(double);
+    double* d_img = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_img), bytes));
+    hipError_t e = hipMemcpyAsync(d_img, img, bytes, hipMemcpyHostToDevice, d->stream);   // untouched pixels keep the caller's values
+    int rc = e == hipSuccess ? mcpt_render_device(d, p, d_img, stats, d->stream) : fail(MCPT_ERR_HIP, hipGetErrorString(e));
+    if (rc == MCPT_OK) {
+        e = hipMemcpyAsync(img, d_img, bytes, hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        if (e != hipSuccess) rc = fail(MCPT_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_img);
+    return rc;
+}
+
+int mcpt_sample_radiance(mcpt_device* d, uint64_t seed, const int32_t* pix, const int32_t* k, int64_t n, double* rgb)
+{
+    if (!d || !pix || !k || !rgb || n < 0) return fail(MCPT_ERR_ARG, "bad argument");
+    if (n == 0) return MCPT_OK;
+    for (int64_t i = 0; i < n; i++)
+        if (pix[i] < 0 || pix[i] >= d->width * d->height) return fail(MCPT_ERR_ARG, "pixel index out of range");
+    HIP_TRY(hipSetDevice(d->ordinal));
+    int rc = ensure_dirs(d, d->stream);
+    if (rc) return rc;
+    int32_t *d_pix = nullptr, *d_k = nullptr;
+    double* d_rgb = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_pix); (void)hipFree(d_k); (void)hipFree(d_rgb); };
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_pix), size_t(n) * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_k), size_t(n) * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rgb), size_t(n) * 24);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pix, pix, size_t(n) * 4, hipMemcpyHostToDevice, d->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_k, k, size_t(n) * 4, hipMemcpyHostToDevice, d->stream);
+    if (e == hipSuccess) {
+        launch_sample_radiance(d->ds, seed, d->dirs, d_pix, d_k, n, d_rgb, d->ctr, d->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_rgb, size_t(n) * 24, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(MCPT_ERR_HIP, hipGetErrorString(e));
+    return MCPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ output
+int mcpt_quantize_rgb8(const double* img, int64_t n, uint8_t* rgb8)
+{
+    if (!img || !rgb8 || n < 0) return fail(MCPT_ERR_ARG, "bad argument");
+    for (int64_t i = 0; i < n; i++) {
+        double v = img[i] * 255;                  // imshow, MTPC.cpp:26-28: (unsigned char)glm::clamp(v*255, 0.0, 255.0)
+        v = std::max(v, 0.0);
+        v = std::min(v, 255.0);
+        rgb8[i] = static_cast<uint8_t>(v);
+    }
+    return MCPT_OK;
+}
+
+int64_t mcpt_png_encode(const uint8_t* rgb8, int32_t w, int32_t h, uint8_t* out, int64_t cap)
+{
+    if (!rgb8 || !out) return fail(MCPT_ERR_ARG, "null argument");
+    const int64_t n = png_encode(rgb8, w, h, out, cap);
+    if (n < 0) return fail(MCPT_ERR_ARG, "png: bad size or buffer too small");
+    return n;
+}
+
+int mcpt_write_png(const char* file, const uint8_t* rgb8, int32_t w, int32_t h)
+{
+    if (!file || !rgb8 || w <= 0 || h <= 0) return fail(MCPT_ERR_ARG, "bad argument");
+    const int64_t cap = 8 + 25 + 12 + 2 + int64_t(h) * (int64_t(w) * 3 + 6) + 4 + 12 + 16;
+    std::vector<uint8_t> buf(static_cast<size_t>(cap));
+    const int64_t n = png_encode(rgb8, w, h, buf.data(), cap);
+    if (n < 0) return fail(MCPT_ERR_ARG, "png: width too large for one stored block per row");
+    FILE* fp = std::fopen(file, "wb");
+    if (!fp) return fail(MCPT_ERR_IO, std::string("cannot open ") + file);
+    const bool ok = std::fwrite(buf.data(), 1, size_t(n), fp) == size_t(n);
+    std::fclose(fp);                              // the reference never closes it (truncated veach-mis PNGs)
+    return ok ? MCPT_OK : fail(MCPT_ERR_IO, std::string("short write to ") + file);
+}
+
+// ------------------------------------------------------------------------------------------------ render_scene
+int mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options* opt, mcpt_stats* stats)
+{
+    if (!path || !filename || spp <= 0) return fail(MCPT_ERR_ARG, "bad argument");
+    mcpt_render_scene_options o{};
+    if (opt) o = *opt;
+    const bool talk = !o.quiet;
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    mcpt_scene* sc = nullptr;
+    int rc = mcpt_scene_load(path, filename, &sc);
+    if (rc) return rc;
+    if (o.width > 0 && o.height > 0) mcpt_scene_set_resolution(sc, o.width, o.height);
+    const Scene& s = sc->s;
+    if (talk) {
+        std::printf("%s%s.obj\nnumber of materials = %zu\nnumber of vertices = %zu\nnumber of faces = %zu\n", path, filename,
+                    s.materials.size(), s.v.size(), s.faces.size());
+        std::printf("Total real = %d\nBuild BVH success\n", s.bi.Nr);
+    }
+    mcpt_device* dev = nullptr;
+    rc = mcpt_device_create(sc, o.device, &dev);
+    if (rc) { mcpt_scene_free(sc); return rc; }
+    const auto t1 = clk::now();
+    if (talk) std::printf("Phase 1(read scene + bvh build) time cost = %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
+    std::vector<double> img(size_t(s.width) * s.height * 3, 0.0);
+    mcpt_render_params rp{};
+    rp.spp = spp; rp.seed = o.seed; rp.world = 1;
+    mcpt_stats local{};
+    rc = mcpt_render(dev, &rp, img.data(), &local);
+    const auto t2 = clk::now();
+    if (rc == MCPT_OK) {
+        if (talk) std::printf("Phase 2(ray tracing) = %.3f ms\n", std::chrono::duration<double, std::milli>(t2 - t1).count());
+        std::vector<uint8_t> rgb(img.size());
+        mcpt_quantize_rgb8(img.data(), int64_t(img.size()), rgb.data());
+        const std::string prefix = o.output_prefix ? std::string(o.output_prefix) : std::string("../result/") + filename;
+        const std::string file = prefix + "-SPP" + std::to_string(spp) + ".png";       // imshow, MTPC.cpp:17-20
+        rc = mcpt_write_png(file.c_str(), rgb.data(), s.width, s.height);
+    }
+    if (stats) *stats = local;
+    mcpt_device_free(dev);
+    mcpt_scene_free(sc);
+    return rc;
+}
+
+int mcpt_render_scene(const char* path, const char* filename, int32_t spp)
+{
+    return mcpt_render_scene_ex(path, filename, spp, nullptr, nullptr);
+}
+
+}  // extern "C"

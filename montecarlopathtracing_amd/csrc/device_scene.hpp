@@ -1,0 +1,78 @@
+// Records of a scene as they sit in HBM.  Traversal touches one node or one triangle per lane per step,
+// each lane somewhere else in the tree, so the unit of access is a whole record that fills exactly one or two
+// 64-byte memory segments (array-of-records per node / per triangle, SoA across kinds of data: boxes, hit-test
+// geometry, shading attributes, materials, light tables and textures live in separate arrays so that a step
+// only pulls the bytes it needs).
+#pragma once
+#include <cstdint>
+
+namespace mcpt {
+
+// One real BVH node, compact level order (index = BVH::findIndex).  48 bytes of box padded to one 64-B segment.
+struct alignas(64) DNode {
+    double mn[3];
+    double mx[3];
+    double pad[2];
+};
+
+// Hit-test geometry of leaf k (Morton order): 96 bytes used by intersect(Ray,Face) + ids.  128 B = 2 segments.
+struct alignas(128) DTri {
+    double v1[3], v2[3], v3[3];
+    double n[3];               // Face::norm
+    int32_t material;
+    int32_t face;              // .obj index
+    int32_t pad[6];
+};
+
+// Shading attributes of leaf k, read once per accepted closest hit.
+struct alignas(128) DTriShade {
+    double vn1[3], vn2[3], vn3[3];
+    double vt1[2], vt2[2], vt3[2];
+    double pad;
+};
+
+struct alignas(16) DMaterial {
+    double kd[3], ks[3];
+    double Ns, Ni;
+    int32_t has_map, map_w, map_h, light;
+    int64_t tex_offset;        // byte offset into the texel pool (BGR rows)
+    int64_t pad;
+};
+
+// One triangle of an emitter, in the order of Material::f (the order shade() walks the area CDF in).
+struct alignas(16) DLightTri {
+    double v1[3], v2[3], v3[3];
+    double vn1[3], vn2[3], vn3[3];
+};
+
+struct alignas(16) DLight {
+    double radiance[3];
+    double total_area;
+    int32_t material, ntri, first, cdf_sorted;   // first = offset into light_tris / light_cdf
+};
+
+struct DCamera {                                   // generateImg's frame, pathTracing.cpp:276-294
+    double eye[3], start_point[3], pdx[3], pdy[3];
+    int32_t width, height;
+};
+
+struct DScene {
+    const DNode* nodes;
+    const DTri* tris;
+    const DTriShade* shade;
+    const DMaterial* materials;
+    const DLight* lights;
+    const DLightTri* light_tris;
+    const double* light_cdf;
+    const uint8_t* texels;
+    int32_t t, Lv, Level, Nr, num_lights, num_materials;
+    double area0;                                  // range of the frozen static u1 (Q1)
+    DCamera cam;
+};
+
+// device-side counters (one cache line)
+struct DCounters {
+    unsigned long long rays_primary, rays_shadow, rays_bounce, node_visits, tri_tests, shade_calls, samples, max_depth;
+};
+
+}  // namespace mcpt

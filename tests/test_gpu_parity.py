@@ -1,0 +1,89 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars: closest-hit face index, t, p, pn BIT-EXACT (fp64, no FMA contraction); per-sample radiance within
+1e-9 relative (libm differences between glibc and the device math library; discrete flips are counted and
+must stay below 1e-4 of the samples); images within the same tolerance per pixel."""
+import numpy as np
+import pytest
+
+from conftest import SCENES, make_rays
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-9
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module", params=["cornell-box", "veach-mis"])
+def pair(request, oracle, mcpt):
+    name = request.param
+    w, h = (160, 90)
+    osc = oracle.OracleScene(SCENES + name, texture_dir=SCENES, width=w, height=h)
+    sc = mcpt.Scene(SCENES, name, width=w, height=h)
+    dev = mcpt.Device(sc, 0)
+    yield name, osc, sc, dev
+    dev.close()
+    sc.close()
+    osc.close()
+
+
+def test_closest_hit_bit_exact(pair, oracle, mcpt):
+    name, osc, sc, dev = pair
+    rays = make_rays(osc, 40000, seed=11)
+    of, ot, op, opn = osc.trace_closest(rays)
+    st = mcpt.Stats()
+    gf, gt, gp, gpn = dev.ray_intersect(rays, stats=st)
+    assert np.array_equal(of, gf), "closest-hit face index differs on %d rays" % int((of != gf).sum())
+    hit = of >= 0
+    assert hit.sum() > 1000
+    assert np.array_equal(_bits(ot[hit]), _bits(gt[hit]))
+    assert np.array_equal(_bits(op[hit]), _bits(gp[hit]))
+    assert np.array_equal(_bits(opn[hit]), _bits(gpn[hit]))
+    ost = oracle.Stats()
+    osc.trace_closest(rays, stats=ost)
+    assert st.node_visits == ost.box_tests and st.tri_tests == ost.tri_tests
+
+
+def test_sample_radiance(pair, oracle, mcpt):
+    name, osc, sc, dev = pair
+    rng = np.random.default_rng(5)
+    n = 3000
+    pix = rng.integers(0, osc.width * osc.height, size=n).astype(np.int32)
+    k = rng.integers(0, 64, size=n).astype(np.int32)
+    g = dev.sample_radiance(77, pix, k)
+    o = np.array([osc.sample_radiance(77, int(p // osc.width), int(p % osc.width), int(kk)) for p, kk in zip(pix, k)])
+    scale = np.maximum(np.abs(o).max(axis=1), 1e-12)
+    err = np.abs(g - o).max(axis=1) / scale
+    flips = int((err > REL_TOL).sum())
+    assert flips <= max(1, n // 10000 + 1), "radiance mismatch on %d/%d samples (max rel %.3e)" % (flips, n, err.max())
+    assert np.abs(o).sum() > 0
+
+
+def test_image_matches_oracle(pair, oracle, mcpt):
+    name, osc, sc, dev = pair
+    spp = 8
+    ost = oracle.Stats()
+    ref = osc.render(spp, seed=3, stats=ost)
+    st = mcpt.Stats()
+    img = dev.generateImg(spp, seed=3, stats=st)
+    assert img.shape == ref.shape
+    scale = np.maximum(np.abs(ref), 1e-6)
+    rel = np.abs(img - ref) / scale
+    bad = int((rel > 1e-6).sum())      # float accumulator: 1 ulp of fp32 ~ 6e-8
+    assert bad <= max(3, img.size // 20000), "%d pixel channels differ (max rel %.3e)" % (bad, rel.max())
+    # same work was done
+    assert st.rays_shadow == ost.rays_shadow and st.rays_bounce == ost.rays_bounce
+    assert np.array_equal(mcpt.imshow_rgb8(img) != oracle.quantize(ref), np.zeros_like(img, dtype=bool)) or \
+        int((mcpt.imshow_rgb8(img) != oracle.quantize(ref)).sum()) <= 8
+
+
+def test_partition_independent(pair, mcpt):
+    name, osc, sc, dev = pair
+    full = dev.generateImg(4, seed=9)
+    parts = np.zeros_like(full)
+    for r in range(3):
+        dev.generateImg(4, seed=9, rank=r, world=3, img=parts)
+    assert np.array_equal(_bits(full), _bits(parts))
