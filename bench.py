@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and sec/frame of cornell-box at 1280x720, SPP 256 (BASELINE.json configs[1]).
+
+One step = one whole frame (the per-pixel integrator loop over every pixel and sample) rendered from the scene
+resident in HBM; the frame is tile-partitioned over the N GPUs of one node and gathered to rank 0 (RCCL) inside
+the timed region.  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per unit of work (DESIGN.md "Roofline"): what one ray query must read/write at minimum
+BYTES_PER_NODE = 48      # 6 fp64 box planes of a visited node
+BYTES_PER_TRI = 104      # 9 fp64 vertices + 3 fp64 normal + material/face ids of a tested triangle
+BYTES_PER_RAY = 64       # ray origin/direction in, hit record out
+BYTES_PER_SAMPLE = 48    # 24 B radiance written by the shading kernel + 24 B read back by the fold
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def write_scene_dir(name, width, height):
+    """Scene directory whose .camera has width/height replaced (the parser reads them, sceneManagement.cpp:233-240)."""
+    src = os.path.join(ROOT, "scenes")
+    d = tempfile.mkdtemp(prefix="mcpt_bench_")
+    for ext in (".obj", ".mtl"):
+        os.symlink(os.path.join(src, name + ext), os.path.join(d, name + ext))
+    for f in os.listdir(src):
+        if f.endswith(".ppm") or f.endswith(".jpg"):
+            os.symlink(os.path.join(src, f), os.path.join(d, f))
+    with open(os.path.join(src, name + ".camera"), "rb") as fh:
+        lines = fh.read().decode().replace("\r", "").split("\n")
+    out = []
+    for ln in lines:
+        if ln.startswith("width"):
+            ln = "width %d" % width
+        elif ln.startswith("height"):
+            ln = "height %d" % height
+        out.append(ln)
+    with open(os.path.join(d, name + ".camera"), "w") as fh:
+        fh.write("\n".join(out))
+    return d + os.sep
+
+
+def one_socket_cpus():
+    """Logical CPUs that are the first hardware thread of each physical core of socket 0 (within our affinity mask)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    try:
+        seen, pick = set(), []
+        for c in allowed:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+            if pkg == 0 and core not in seen:
+                seen.add(core)
+                pick.append(c)
+        return pick or allowed
+    except OSError:
+        return allowed
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(scene_dir, name, seed, target_seconds=15.0):
+    """The oracle (CPU port of the reference, reference-like cost: primary ray re-traced per sample, light CDF
+    rebuilt per shade call) on a bounded sample of the same workload: every 8th row of the frame, all columns,
+    at an SPP sized for ~target_seconds, on the physical cores of one socket (OpenMP over row x 64-column blocks;
+    the reference itself forks <= 8 threads per pixel, MTPC/pathTracing.cpp:303)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    cpus = one_socket_cpus()
+    old = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, cpus)
+    try:
+        cores = len(cpus)
+        osc = O.OracleScene(scene_dir + name, texture_dir=scene_dir)
+        stride = 8
+        img = np.zeros((osc.height, osc.width, 3))
+        # calibrate: SPP 1 pass, then size the timed pass
+        st0 = O.Stats()
+        t0 = time.time()
+        osc.render_strided(1, seed, stride, faithful_cost=True, nthreads=cores, stats=st0, img=img)
+        dt0 = max(time.time() - t0, 1e-3)
+        spp = int(min(256, max(2, round(target_seconds / dt0))))
+        st = O.Stats()
+        t0 = time.time()
+        osc.render_strided(spp, seed, stride, faithful_cost=True, nthreads=cores, stats=st, img=img)
+        dt = time.time() - t0
+    finally:
+        os.sched_setaffinity(0, old)
+    rays = st.rays
+    nrows = (osc.height + stride - 1) // stride
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%s %dx%d, rows 0,%d,%d,.. (%d rows, all columns) at SPP %d, seed %d: %d samples, %d rays in %.1f s; oracle in "
+                      "reference-cost mode (primary ray re-traced per sample, light CDF rebuilt per shade call); OpenMP over "
+                      "row x 64-column blocks on %d threads = physical cores of socket 0 (%s)"
+                      % (name, osc.width, osc.height, stride, 2 * stride, nrows, spp, seed, st.samples, rays, dt, cores, cpu_model()),
+            "samples_per_s": st.samples / dt, "rays_per_sample": rays / max(1, st.samples), "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell-box")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-png", default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import montecarlopathtracing_amd as M
+    from montecarlopathtracing_amd.dist import DistributedRenderer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    tdev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
+
+    scene_dir = write_scene_dir(args.scene, args.width, args.height)
+    scene = M.Scene(scene_dir, args.scene)
+    dev = M.Device(scene, local_rank)
+    rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rr.render(args.spp, args.seed)
+    sync()
+    stats = M.Stats()
+    tot = {"rays": 0, "node_visits": 0, "tri_tests": 0, "samples": 0, "ms_trace": 0.0, "launches": 0, "rays_primary": 0,
+           "rays_shadow": 0, "rays_bounce": 0}
+    t0 = time.perf_counter()
+    frame = None
+    for _ in range(args.steps):
+        frame = rr.render(args.spp, args.seed, stats=stats)
+        for k in tot:
+            tot[k] += getattr(stats, k)
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    vals = torch.tensor([elapsed] + [float(tot[k]) for k in ("rays", "node_visits", "tri_tests", "samples", "launches")] + [tot["ms_trace"]],
+                        dtype=torch.float64, device=tdev)
+    if world > 1:
+        mx = vals.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = vals.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        rays, nodes, tris, samples, launches = (float(sm[i]) for i in range(1, 6))
+        ms_trace_max = float(mx[6])
+    else:
+        rays, nodes, tris, samples, launches = (float(vals[i]) for i in range(1, 6))
+        ms_trace_max = tot["ms_trace"]
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        sec_per_frame = elapsed / steps
+        value = rays / elapsed / 1e6
+        # dominant kernel = k_shade_samples (one launch per pixel chunk); algorithmic bytes of its launches
+        prim = tot["rays_primary"]
+        alg_bytes_rank0 = (BYTES_PER_NODE * tot["node_visits"] + BYTES_PER_TRI * tot["tri_tests"] + BYTES_PER_RAY * tot["rays"]
+                           + BYTES_PER_SAMPLE * tot["samples"])
+        n_launch = max(1, tot["launches"])
+        avg_ms = tot["ms_trace"] / n_launch
+        achieved = (alg_bytes_rank0 / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s on cornell-box 1280x720 SPP=256 (closest-hit queries actually traced / wall time incl. gather)",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sec_per_frame * 1e3, "sec_per_frame": sec_per_frame, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "reference scene %s.obj (in repo under scenes/), .camera rewritten to %dx%d, seed %d" % (args.scene, args.width, args.height, args.seed),
+            "config": {"workload": "%s %dx%d SPP=%d" % (args.scene, args.width, args.height, args.spp), "seed": args.seed,
+                       "partition": "32x8-pixel tiles round-robin over ranks, RCCL gather to rank 0",
+                       "primary_rays": "traced once per pixel (identical for every sample: the reference has no jitter)"},
+            "rays_per_frame": rays / steps, "samples_per_frame": samples / steps,
+            "nodes_per_ray": nodes / max(1.0, rays), "tris_per_ray": tris / max(1.0, rays),
+            "roofline": {"bound": "hbm", "kernel": "k_shade_samples", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": tot["launches"],
+                         "algorithmic_bytes_per_launch": alg_bytes_rank0 / n_launch,
+                         "note": "rank-0 launches; bytes = 48 B x node visits + 104 B x triangle tests + 64 B x rays + 48 B x samples, from the run's own device counters; the scene (2 MB of nodes, 2 MB of triangles) is L2-resident, see DESIGN.md"},
+        }
+        if args.save_png and frame is not None:
+            img = frame.cpu().numpy()
+            M.write_png(args.save_png, M.imshow_rgb8(img))
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(scene_dir, args.scene, args.seed)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu_mrays"] = value / cb["value"]
+            # frame-time ratio: CPU seconds for the full frame extrapolated linearly in samples
+            cpu_frame_s = (args.width * args.height * args.spp) / cb["samples_per_s"]
+            out["cpu_sec_per_frame_extrapolated"] = cpu_frame_s
+            out["gpu_over_cpu_frame_time"] = cpu_frame_s / sec_per_frame
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1107,3 +1107,30 @@ int64_t orc_png_encode(const uint8_t* img, int w, int h, uint8_t* out, int64_t c
     begin(&pw, "IEND", 0); end(&pw);
     return pw.ovf ? -1 : pw.pos;
 }
+
+/* Same as orc_render for rows 0, stride, 2*stride, ... (all columns): the bounded CPU-baseline sample.
+ * Work items are (sampled row, 64-column block) pairs handed out dynamically to the OpenMP team. */
+void orc_render_strided(const orc_scene* s, int spp, uint64_t seed, int row_stride, int faithful_cost, int nthreads,
+                        int unused, double* img, orc_stats* st)
+{
+    (void)unused;
+    const int nrows = (s->height + row_stride - 1) / row_stride;
+    const int cb = 64, ncb = (s->width + cb - 1) / cb;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    orc_stats total; memset(&total, 0, sizeof total);
+#pragma omp parallel
+    {
+        orc_stats local; memset(&local, 0, sizeof local);
+#pragma omp for schedule(dynamic, 1)
+        for (int w = 0; w < nrows * ncb; w++) {
+            const int r = (w / ncb) * row_stride, c0 = (w % ncb) * cb;
+            const int c1 = c0 + cb < s->width ? c0 + cb : s->width;
+            orc_render(s, spp, seed, r, r + 1, c0, c1, faithful_cost, -1, img, &local);
+        }
+#pragma omp critical
+        stats_add(&total, &local);
+    }
+    if (st) stats_add(st, &total);
+}

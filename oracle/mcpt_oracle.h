@@ -16,7 +16,7 @@
  *   - loader/BVH/traversal/shading: the reference TUs need glm, OpenCV and Eigen headers
  *     that this image lacks, so they are unbuildable here; the reference ships no tests or
  *     golden vectors.  The only reference outputs are the time-seeded renders under
- *     result/*.png; the oracle is pinned STATISTICALLY against block means of those
+ *     result/ *.png; the oracle is pinned STATISTICALLY against block means of those
  *     (tests/golden/published_*.npz).  Bitwise parity of those stages: PARITY UNPINNED.
  *
  * Documented deviations from the reference (all needed for reproducibility / to avoid UB):
@@ -105,6 +105,10 @@ void orc_primary_ray(const orc_scene*, int row, int col, double ray6[6]);
  * (same result, reference-like cost; used for the CPU baseline).  nthreads<=0 -> OpenMP default. */
 void orc_render(const orc_scene*, int spp, uint64_t seed, int row0, int row1, int col0, int col1,
                 int faithful_cost, int nthreads, double* img, orc_stats* st);
+
+/* rows 0, stride, 2*stride, ... only (bounded CPU-baseline sample); OpenMP over the sampled rows */
+void orc_render_strided(const orc_scene*, int spp, uint64_t seed, int row_stride, int faithful_cost, int nthreads,
+                        int unused, double* img, orc_stats* st);
 
 /* ---- output: MTPC/MTPC.cpp:10-33, MTPC/svpng.inc:77-107 ---- */
 void orc_quantize(const double* img, int64_t n, uint8_t* rgb8);

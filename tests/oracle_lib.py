@@ -71,6 +71,8 @@ def lib():
         L.orc_primary_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_double), C.POINTER(Stats)]
+        L.orc_render_strided.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_double), C.POINTER(Stats)]
         L.orc_quantize.argtypes = [C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_uint8)]
         L.orc_png_encode.restype = C.c_int64
         L.orc_png_encode.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int64]
@@ -186,6 +188,17 @@ class OracleScene:
         lib().orc_render(self.h, spp, seed, r0, r1, c0, c1, int(faithful_cost), nthreads, _ptr(img, C.c_double),
                          C.byref(stats) if stats is not None else None)
         return img
+
+
+def _render_strided(self, spp, seed, row_stride, faithful_cost=True, nthreads=0, stats=None, img=None):
+    if img is None:
+        img = np.zeros((self.height, self.width, 3))
+    lib().orc_render_strided(self.h, spp, seed, row_stride, int(faithful_cost), nthreads, 0, _ptr(img, C.c_double),
+                             C.byref(stats) if stats is not None else None)
+    return img
+
+
+OracleScene.render_strided = _render_strided
 
 
 def quantize(img):
