@@ -99,9 +99,22 @@ int  mcpt_scene_get_material(const mcpt_scene*, int32_t m, char name[64], double
 int  mcpt_scene_get_light(const mcpt_scene*, int32_t i, char name[64], double radiance[3], int32_t* material, double* total_area);
 uint32_t mcpt_morton_code(float x, float y, float z);                         /* getMortonCode, MTPC/morton code.cpp:22-32 */
 
+/* Diagnostic: builds the fast closest-hit hierarchy (accel_build.cpp) on the host and reports its shape.
+ * leaf_order[num_faces] (may be NULL) = reference leaf index held by every slot of its triangle list;
+ * nesting_ok = 1 when every stored child box contains everything below it (what the culling argument needs). */
+int  mcpt_scene_fast_bvh_stats(const mcpt_scene*, int32_t* n_nodes, int32_t* max_depth, int32_t* leaf_order, int32_t* nesting_ok);
+
 /* ---- device ---- */
 int  mcpt_device_create(const mcpt_scene*, int32_t device_ordinal, mcpt_device** out);
 void mcpt_device_free(mcpt_device*);
+/* Which walk the closest-hit queries use.  Both return identical results (tests/test_gpu_parity.py).
+ *   MCPT_TRACE_FAST (default): SAH hierarchy over the reference's leaf boxes, conservative culling, distance pruning,
+ *                              the reference's own fp64 leaf-box / triangle tests on every candidate;
+ *   MCPT_TRACE_REFERENCE     : the reference's implicit Morton tree in the reference's visiting order
+ *                              (bvh_intersect, MTPC/pathTracing.cpp:334-374), no pruning. */
+#define MCPT_TRACE_FAST      0
+#define MCPT_TRACE_REFERENCE 1
+int  mcpt_device_set_trace_mode(mcpt_device*, int32_t mode);
 
 /* ---- closest hit (ray_intersect) ---- */
 /* rays: n x 6 doubles (origin xyz, direction xyz).  face[n] = .obj face index or -1, t[n], p[n*3], pn[n*3];

@@ -57,8 +57,8 @@ EXPORTS = [
     "mcpt_version", "mcpt_last_error", "mcpt_device_count",
     "mcpt_scene_load", "mcpt_scene_free", "mcpt_scene_set_resolution", "mcpt_scene_get_info", "mcpt_scene_get_faces",
     "mcpt_scene_get_leaf_order", "mcpt_scene_get_bvh_nodes", "mcpt_scene_find_index", "mcpt_scene_get_material",
-    "mcpt_scene_get_light", "mcpt_morton_code",
-    "mcpt_device_create", "mcpt_device_free",
+    "mcpt_scene_get_light", "mcpt_morton_code", "mcpt_scene_fast_bvh_stats",
+    "mcpt_device_create", "mcpt_device_free", "mcpt_device_set_trace_mode",
     "mcpt_trace_closest", "mcpt_trace_closest_device",
     "mcpt_render", "mcpt_render_device", "mcpt_sample_radiance", "mcpt_owned_pixels",
     "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode",
@@ -100,9 +100,11 @@ def lib():
     L.mcpt_scene_get_light.argtypes = [P, C.c_int32, C.c_char_p, D, I32, D]
     L.mcpt_morton_code.restype = C.c_uint32
     L.mcpt_morton_code.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.mcpt_scene_fast_bvh_stats.argtypes = [P, I32, I32, I32, I32]
     L.mcpt_device_create.argtypes = [P, C.c_int32, C.POINTER(P)]
     L.mcpt_device_free.argtypes = [P]
     L.mcpt_device_free.restype = None
+    L.mcpt_device_set_trace_mode.argtypes = [P, C.c_int32]
     L.mcpt_trace_closest.argtypes = [P, D, C.c_int64, I32, D, D, D, C.POINTER(Stats)]
     L.mcpt_trace_closest_device.argtypes = [P, P, C.c_int64, P, P, P, P, P]
     L.mcpt_render.argtypes = [P, C.POINTER(RenderParams), D, C.POINTER(Stats)]

@@ -8,6 +8,9 @@ from . import _lib
 from ._lib import McptError, RenderParams, RenderSceneOptions, SceneInfo, Stats, check, lib
 
 
+TRACE_FAST, TRACE_REFERENCE = 0, 1
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
@@ -88,6 +91,14 @@ class Scene:
         check(lib().mcpt_scene_get_light(self._h, i, name, _p(rad, C.c_double), _p(m, C.c_int32), _p(a, C.c_double)))
         return name.value.decode(), rad, int(m[0]), float(a[0])
 
+    def fast_bvh_stats(self):
+        n = np.zeros(1, dtype=np.int32)
+        d = np.zeros(1, dtype=np.int32)
+        ok = np.zeros(1, dtype=np.int32)
+        order = np.zeros(self.info.num_faces, dtype=np.int32)
+        check(lib().mcpt_scene_fast_bvh_stats(self._h, _p(n, C.c_int32), _p(d, C.c_int32), _p(order, C.c_int32), _p(ok, C.c_int32)))
+        return int(n[0]), int(d[0]), order, bool(ok[0])
+
     def owned_pixels(self, rank=0, world=1, tile_w=0, tile_h=0):
         rp = RenderParams(1, 0, rank, world, tile_w, tile_h, 0)
         n = lib().mcpt_owned_pixels(self._h, C.byref(rp), None)
@@ -114,6 +125,10 @@ class Device:
             self._h = None
 
     __del__ = close
+
+    def set_trace_mode(self, mode):
+        """TRACE_FAST (default) or TRACE_REFERENCE: which walk answers closest-hit queries (same results)."""
+        check(lib().mcpt_device_set_trace_mode(self._h, mode))
 
     def ray_intersect(self, rays, stats=None):
         """Batch of ray_intersect (MTPC/pathTracing.cpp:382): rays [n,6] -> face (.obj index or -1), t, p, pn."""

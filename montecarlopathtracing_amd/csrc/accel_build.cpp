@@ -1,0 +1,196 @@
+// Host build of the traversal structure the fast closest-hit kernel walks.
+//
+// Why a second structure may be used at all: for a ray whose direction components are all non-zero the reference's
+// result does not depend on the shape of its tree.  Its box test (sceneManagement.cpp:340-391) is monotone under
+// box inclusion in IEEE arithmetic -- a parent's box contains its children's, "(b-o)/d" is a composition of monotone
+// correctly-rounded operations, so a leaf whose own box passes has every ancestor passing as well -- hence
+//     ray_intersect(ray) = lexicographic min over leaves k of (t_k, k)
+//                          among { k : box test of leaf k passes, triangle test passes, t_k > 0 }      (pathTracing.cpp:334-374)
+// (the reference visits leaves in ascending k and replaces only on strict '<').  Any structure that (a) reaches every
+// leaf that can be that minimum and (b) evaluates the reference's own fp64 tests on it returns the identical answer.
+// Rays with a zero/denormal/non-finite component (0/0 -> NaN breaks monotonicity) take the reference-shaped walk.
+//
+// This file builds (a): a binary SAH hierarchy over the reference's leaf boxes, at most kMaxLeaf triangles per leaf,
+// depth-bounded so the traversal stack fits the LDS budget, children's boxes stored in the parent so one record
+// fetch tests both children.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "accel_build.hpp"
+
+namespace mcpt {
+namespace {
+
+constexpr int kBins = 16;
+constexpr double kCostNode = 1.0;   // relative cost of one inner step (two conservative box tests)
+constexpr double kCostTri = 1.6;    // relative cost of one leaf triangle (cheap box reject + some exact tests)
+
+struct Box {
+    double lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<double>::infinity(); hi[a] = -lo[a]; } }
+    void grow(const Box& b) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    double half_area() const
+    {
+        const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Builder {
+    const std::vector<Box>& prim;       // exact leaf boxes, indexed by leaf (Morton) order k
+    std::vector<Vec3> cen;
+    std::vector<int32_t> idx;           // permutation being partitioned
+    FastBvh& out;
+
+    Builder(const std::vector<Box>& p, FastBvh& o) : prim(p), out(o)
+    {
+        cen.resize(p.size());
+        for (size_t i = 0; i < p.size(); i++)
+            cen[i] = Vec3{0.5 * (p[i].lo[0] + p[i].hi[0]), 0.5 * (p[i].lo[1] + p[i].hi[1]), 0.5 * (p[i].lo[2] + p[i].hi[2])};
+        idx.resize(p.size());
+        std::iota(idx.begin(), idx.end(), 0);
+    }
+
+    static int ceil_log2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+
+    Box bounds(int b, int e) const
+    {
+        Box r; r.reset();
+        for (int i = b; i < e; i++) r.grow(prim[idx[i]]);
+        return r;
+    }
+
+    int32_t make_leaf(int b, int e)
+    {
+        const int32_t start = int32_t(out.leaf_tris.size());
+        // ascending k inside a leaf: ties are then met in the reference's order
+        std::sort(idx.begin() + b, idx.begin() + e);
+        for (int i = b; i < e; i++) out.leaf_tris.push_back(idx[i]);
+        return -1 - ((start << 4) | (e - b - 1));
+    }
+
+    // returns child reference (>=0 inner node index, <0 leaf) for prims [b,e)
+    int32_t build(int b, int e, int depth)
+    {
+        const int n = e - b;
+        out.max_depth = std::max(out.max_depth, depth);
+        if (n <= 1) return make_leaf(b, e);
+        const bool force_balanced = depth + ceil_log2(n) >= kFastMaxDepth - 1;
+        Box cb; cb.reset();
+        for (int i = b; i < e; i++) {
+            const Vec3& c = cen[idx[i]];
+            cb.lo[0] = std::min(cb.lo[0], c.x); cb.hi[0] = std::max(cb.hi[0], c.x);
+            cb.lo[1] = std::min(cb.lo[1], c.y); cb.hi[1] = std::max(cb.hi[1], c.y);
+            cb.lo[2] = std::min(cb.lo[2], c.z); cb.hi[2] = std::max(cb.hi[2], c.z);
+        }
+        int mid = -1;
+        if (!force_balanced) {
+            const Box nb = bounds(b, e);
+            const double parent_area = nb.half_area();
+            double best = std::numeric_limits<double>::infinity();
+            int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < 3; a++) {
+                const double ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0)) continue;
+                Box bb[kBins]; int cnt[kBins];
+                for (int k = 0; k < kBins; k++) { bb[k].reset(); cnt[k] = 0; }
+                const double scale = kBins * (1.0 - 1e-12) / ext;
+                auto ca = [&](int i) { const Vec3& c = cen[idx[i]]; return a == 0 ? c.x : (a == 1 ? c.y : c.z); };
+                for (int i = b; i < e; i++) {
+                    int k = int((ca(i) - cb.lo[a]) * scale);
+                    k = std::min(std::max(k, 0), kBins - 1);
+                    bb[k].grow(prim[idx[i]]); cnt[k]++;
+                }
+                double right_area[kBins]; int right_cnt[kBins];
+                Box acc; acc.reset(); int c = 0;
+                for (int k = kBins - 1; k > 0; k--) { acc.grow(bb[k]); c += cnt[k]; right_area[k] = acc.half_area(); right_cnt[k] = c; }
+                acc.reset(); c = 0;
+                for (int k = 0; k + 1 < kBins; k++) {
+                    acc.grow(bb[k]); c += cnt[k];
+                    if (c == 0 || right_cnt[k + 1] == 0) continue;
+                    const double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
+                    if (cost < best) { best = cost; best_axis = a; best_bin = k; }
+                }
+            }
+            if (best_axis >= 0) {
+                const double split_cost = kCostNode + kCostTri * best / std::max(parent_area, 1e-300);
+                if (n <= kFastMaxLeaf && kCostTri * n <= split_cost) return make_leaf(b, e);
+                const int a = best_axis;
+                const double ext = cb.hi[a] - cb.lo[a];
+                const double scale = kBins * (1.0 - 1e-12) / ext;
+                auto it = std::partition(idx.begin() + b, idx.begin() + e, [&](int32_t p) {
+                    const Vec3& c = cen[p];
+                    const double v = a == 0 ? c.x : (a == 1 ? c.y : c.z);
+                    int k = int((v - cb.lo[a]) * scale);
+                    k = std::min(std::max(k, 0), kBins - 1);
+                    return k <= best_bin;
+                });
+                mid = int(it - idx.begin());
+                if (mid == b || mid == e) mid = -1;
+            } else if (n <= kFastMaxLeaf) {
+                return make_leaf(b, e);     // all centroids coincide
+            }
+        }
+        if (mid < 0) {                       // balanced split on the widest centroid axis
+            int a = 0;
+            if (cb.hi[1] - cb.lo[1] > cb.hi[a] - cb.lo[a]) a = 1;
+            if (cb.hi[2] - cb.lo[2] > cb.hi[a] - cb.lo[a]) a = 2;
+            mid = b + n / 2;
+            std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e, [&](int32_t p, int32_t q) {
+                const double vp = a == 0 ? cen[p].x : (a == 1 ? cen[p].y : cen[p].z);
+                const double vq = a == 0 ? cen[q].x : (a == 1 ? cen[q].y : cen[q].z);
+                return vp < vq || (vp == vq && p < q);
+            });
+        }
+        const int32_t self = int32_t(out.nodes.size());
+        out.nodes.emplace_back();
+        const Box lb = bounds(b, mid), rb = bounds(mid, e);
+        const int32_t l = build(b, mid, depth + 1);
+        const int32_t r = build(mid, e, depth + 1);
+        FastNode& nd = out.nodes[self];
+        for (int a = 0; a < 3; a++) { nd.lo[0][a] = lb.lo[a]; nd.hi[0][a] = lb.hi[a]; nd.lo[1][a] = rb.lo[a]; nd.hi[1][a] = rb.hi[a]; }
+        nd.child[0] = l; nd.child[1] = r;
+        return self;
+    }
+};
+
+}  // namespace
+
+void build_fast_bvh(const Scene& s, FastBvh& out)
+{
+    out = FastBvh();
+    const int t = s.bi.t;
+    std::vector<Box> prim(t);
+    const int leaf0 = find_index(s.bi, (1 << s.bi.Level) - 1, s.bi.Level);
+    double amax = 0;
+    for (int k = 0; k < t; k++) {
+        const NodeBox& nb = s.nodes[leaf0 + k];          // the reference's own leaf box of leaf k
+        prim[k].lo[0] = nb.min_x; prim[k].lo[1] = nb.min_y; prim[k].lo[2] = nb.min_z;
+        prim[k].hi[0] = nb.max_x; prim[k].hi[1] = nb.max_y; prim[k].hi[2] = nb.max_z;
+        for (int a = 0; a < 3; a++) {
+            if (std::isfinite(prim[k].lo[a])) amax = std::max(amax, std::fabs(prim[k].lo[a]));
+            if (std::isfinite(prim[k].hi[a])) amax = std::max(amax, std::fabs(prim[k].hi[a]));
+        }
+    }
+    out.scene_absmax = amax;
+    Builder bld(prim, out);
+    out.nodes.reserve(size_t(t));
+    out.leaf_tris.reserve(size_t(t));
+    const int32_t root = bld.build(0, t, 0);
+    if (root < 0) {
+        // a single leaf: wrap it in a root whose second child is an empty leaf with an inverted box
+        FastNode nd{};
+        Box b = bld.bounds(0, t);
+        for (int a = 0; a < 3; a++) {
+            nd.lo[0][a] = b.lo[a]; nd.hi[0][a] = b.hi[a];
+            nd.lo[1][a] = std::numeric_limits<double>::infinity(); nd.hi[1][a] = -std::numeric_limits<double>::infinity();
+        }
+        nd.child[0] = root; nd.child[1] = kFastEmpty;
+        out.nodes.push_back(nd);
+    }
+}
+
+}  // namespace mcpt

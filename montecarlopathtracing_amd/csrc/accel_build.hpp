@@ -1,0 +1,24 @@
+// Traversal structure of the fast closest-hit kernel (see accel_build.cpp for why it is result-identical).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "device_scene.hpp"
+#include "scene.hpp"
+
+namespace mcpt {
+
+constexpr int kFastMaxDepth = 32;          // inner levels; bounds the per-lane LDS stack
+constexpr int kFastMaxLeaf = 4;            // triangles per leaf
+constexpr int32_t kFastEmpty = INT32_MIN;  // child reference of an absent child
+
+struct FastBvh {
+    std::vector<FastNode> nodes;
+    std::vector<int32_t> leaf_tris;        // reference leaf index k of every slot of the leaf triangle list
+    double scene_absmax = 0;               // largest |coordinate| of any leaf box
+    int max_depth = 0;
+};
+
+void build_fast_bvh(const Scene& s, FastBvh& out);
+
+}  // namespace mcpt

@@ -4,12 +4,14 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
 
+#include "accel_build.hpp"
 #include "kernels.hpp"
 #include "scene.hpp"
 
@@ -48,6 +50,8 @@ struct mcpt_device {
     // scene arrays
     DNode* nodes = nullptr; DTri* tris = nullptr; DTriShade* shade = nullptr; DMaterial* materials = nullptr;
     DLight* lights = nullptr; DLightTri* light_tris = nullptr; double* light_cdf = nullptr; uint8_t* texels = nullptr;
+    FastNode* fast_nodes = nullptr; DTri* fast_tris = nullptr;
+    int trace_mode = MCPT_TRACE_FAST;
     // frame state
     int width = 0, height = 0;
     double* dirs = nullptr;                // W*H*3 primary directions
@@ -175,6 +179,42 @@ int mcpt_scene_get_light(const mcpt_scene* h, int32_t i, char name[64], double r
 
 uint32_t mcpt_morton_code(float x, float y, float z) { return morton_code(x, y, z); }
 
+int mcpt_scene_fast_bvh_stats(const mcpt_scene* h, int32_t* n_nodes, int32_t* max_depth, int32_t* leaf_order, int32_t* nesting_ok)
+{
+    if (!h) return fail(MCPT_ERR_ARG, "null scene");
+    FastBvh fb;
+    build_fast_bvh(h->s, fb);
+    if (n_nodes) *n_nodes = int32_t(fb.nodes.size());
+    if (max_depth) *max_depth = fb.max_depth;
+    if (leaf_order) std::copy(fb.leaf_tris.begin(), fb.leaf_tris.end(), leaf_order);
+    if (nesting_ok) {
+        // every child box must contain what hangs below it: inner children by their own child boxes, leaves by the
+        // reference's leaf boxes of their triangles
+        const Scene& s = h->s;
+        const int leaf0 = find_index(s.bi, (1 << s.bi.Level) - 1, s.bi.Level);
+        bool ok = true;
+        for (const FastNode& nd : fb.nodes)
+            for (int c = 0; c < 2; c++) {
+                const int32_t ref = nd.child[c];
+                if (ref == kFastEmpty) continue;
+                auto inside = [&](const double lo[3], const double hi[3]) {
+                    for (int a = 0; a < 3; a++) if (lo[a] < nd.lo[c][a] || hi[a] > nd.hi[c][a]) ok = false;
+                };
+                if (ref >= 0) { inside(fb.nodes[ref].lo[0], fb.nodes[ref].hi[0]); if (fb.nodes[ref].child[1] != kFastEmpty) inside(fb.nodes[ref].lo[1], fb.nodes[ref].hi[1]); }
+                else {
+                    const int r = -1 - ref, first = r >> 4, count = (r & 15) + 1;
+                    for (int i = 0; i < count; i++) {
+                        const NodeBox& b = s.nodes[leaf0 + fb.leaf_tris[first + i]];
+                        const double lo[3] = {b.min_x, b.min_y, b.min_z}, hi[3] = {b.max_x, b.max_y, b.max_z};
+                        inside(lo, hi);
+                    }
+                }
+            }
+        *nesting_ok = ok ? 1 : 0;
+    }
+    return MCPT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ partition
 static void tile_shape(const mcpt_render_params* p, int& tw, int& th, int& rank, int& world)
 {
@@ -214,7 +254,7 @@ void mcpt_device_free(mcpt_device* d)
 {
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
-    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels,
+    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris,
                     d->dirs, d->ctr, d->pixels, d->hits, d->rad};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -254,7 +294,7 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
         double* dst[3] = {q.v1, q.v2, q.v3};
         for (int c = 0; c < 3; c++) { dst[c][0] = vs[c]->x; dst[c][1] = vs[c]->y; dst[c][2] = vs[c]->z; }
         q.n[0] = f.nrm.x; q.n[1] = f.nrm.y; q.n[2] = f.nrm.z;
-        q.material = f.material; q.face = s.order[k];
+        q.material = f.material; q.face = s.order[k]; q.leaf = k;
         double* nd[3] = {a.vn1, a.vn2, a.vn3};
         for (int c = 0; c < 3; c++) { nd[c][0] = f.vn[c].x; nd[c][1] = f.vn[c].y; nd[c][2] = f.vn[c].z; }
         a.vt1[0] = f.vt[0][0]; a.vt1[1] = f.vt[0][1]; a.vt2[0] = f.vt[1][0]; a.vt2[1] = f.vt[1][1]; a.vt3[0] = f.vt[2][0]; a.vt3[1] = f.vt[2][1];
@@ -300,6 +340,19 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
         (rc = upload(mats, &d->materials)) || (rc = upload(lights, &d->lights)) || (rc = upload(ltris, &d->light_tris)) ||
         (rc = upload(lcdf, &d->light_cdf)) || (rc = upload(texels, &d->texels)))
         return rc;
+    // result-identical fast structure (accel_build.cpp)
+    FastBvh fb;
+    build_fast_bvh(s, fb);
+    std::vector<DTri> ftris(fb.leaf_tris.size());
+    for (size_t i = 0; i < fb.leaf_tris.size(); i++) ftris[i] = tris[fb.leaf_tris[i]];
+    bool coords_ok = true;                       // every coordinate zero or within [1e-150, 1e150]
+    for (const FaceRec& f : s.faces)
+        for (int c = 0; c < 3; c++)
+            for (double v : {f.v[c].x, f.v[c].y, f.v[c].z}) {
+                const double a = std::fabs(v);
+                if (!(a == 0.0 || (a >= 1e-150 && a <= 1e150))) coords_ok = false;
+            }
+    if ((rc = upload(fb.nodes, &d->fast_nodes)) || (rc = upload(ftris, &d->fast_tris))) return rc;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->ctr), sizeof(DCounters)));
     HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
 
@@ -309,6 +362,8 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
     S.t = t; S.Lv = s.bi.Lv; S.Level = s.bi.Level; S.Nr = s.bi.Nr;
     S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
     S.area0 = s.area0;
+    S.fast.nodes = d->fast_nodes; S.fast.tris = d->fast_tris; S.fast.absmax = fb.scene_absmax;
+    S.fast.enabled = (coords_ok && fb.max_depth < kFastMaxDepth) ? 1 : 0;
     const CameraFrame cf = camera_frame(s);
     S.cam.eye[0] = cf.eye.x; S.cam.eye[1] = cf.eye.y; S.cam.eye[2] = cf.eye.z;
     S.cam.start_point[0] = cf.start_point.x; S.cam.start_point[1] = cf.start_point.y; S.cam.start_point[2] = cf.start_point.z;
@@ -318,6 +373,13 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
     d->width = s.width; d->height = s.height;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->dirs), size_t(s.width) * s.height * 3 * sizeof(double)));
     *out = d.release();
+    return MCPT_OK;
+}
+
+int mcpt_device_set_trace_mode(mcpt_device* d, int32_t mode)
+{
+    if (!d || (mode != MCPT_TRACE_FAST && mode != MCPT_TRACE_REFERENCE)) return fail(MCPT_ERR_ARG, "bad trace mode");
+    d->trace_mode = mode;
     return MCPT_OK;
 }
 
@@ -345,7 +407,7 @@ int mcpt_trace_closest_device(mcpt_device* d, const double* d_rays, int64_t n, i
 {
     if (!d || (n > 0 && !d_rays) || n < 0) return fail(MCPT_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(d->ordinal));
-    launch_trace_closest(d->ds, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, static_cast<hipStream_t>(stream));
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
     return MCPT_OK;
 }
@@ -368,7 +430,7 @@ int mcpt_trace_closest(mcpt_device* d, const double* rays, int64_t n, int32_t* f
     TRY_OR_CLEAN(hipMemcpyAsync(d_rays, rays, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice, d->stream));
     TRY_OR_CLEAN(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), d->stream));
     TRY_OR_CLEAN(hipEventRecord(d->ev[0], d->stream));
-    launch_trace_closest(d->ds, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->stream);
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->stream);
     TRY_OR_CLEAN(hipGetLastError());
     TRY_OR_CLEAN(hipEventRecord(d->ev[1], d->stream));
     if (face) TRY_OR_CLEAN(hipMemcpyAsync(face, d_face, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));

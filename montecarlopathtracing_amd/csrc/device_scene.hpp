@@ -21,7 +21,8 @@ struct alignas(128) DTri {
     double n[3];               // Face::norm
     int32_t material;
     int32_t face;              // .obj index
-    int32_t pad[6];
+    int32_t leaf;              // k, the reference's leaf (Morton-order) index: tie-break key and index into shade[]
+    int32_t pad[5];
 };
 
 // Shading attributes of leaf k, read once per accepted closest hit.
@@ -29,6 +30,23 @@ struct alignas(128) DTriShade {
     double vn1[3], vn2[3], vn3[3];
     double vt1[2], vt2[2], vt3[2];
     double pad;
+};
+
+// Fast structure: one inner node = both children's boxes + their references, 128 B = one fetch per step.
+// child >= 0: inner node; child < 0: leaf, -1-child = (first << 4) | (count-1) into the permuted triangle array.
+struct alignas(128) FastNode {
+    double lo[2][3];
+    double hi[2][3];
+    int32_t child[2];
+    int32_t pad[6];
+};
+
+struct DFast {
+    const FastNode* nodes;
+    const DTri* tris;          // DTri records permuted into fast-leaf order (leaf field = reference leaf index)
+    double absmax;             // largest |coordinate| in the scene
+    int32_t enabled;           // 0: scene has coordinates outside [1e-150,1e150] -> reference-shaped walk only
+    int32_t pad;
 };
 
 struct alignas(16) DMaterial {
@@ -65,6 +83,7 @@ struct DScene {
     const DLightTri* light_tris;
     const double* light_cdf;
     const uint8_t* texels;
+    DFast fast;
     int32_t t, Lv, Level, Nr, num_lights, num_materials;
     double area0;                                  // range of the frozen static u1 (Q1)
     DCamera cam;

@@ -14,7 +14,7 @@ struct PrimaryHit {                 // closest hit of a pixel's (sample-independ
     double p[3];
 };
 
-void launch_trace_closest(const DScene& S, const double* d_rays, long long n, int32_t* d_face, double* d_t, double* d_p,
+void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long long n, int32_t* d_face, double* d_t, double* d_p,
                           double* d_pn, DCounters* ctr, hipStream_t st);
 void launch_primary_dirs(const DCamera& cam, double* d_dirs, hipStream_t st);
 void launch_primary_hits(const DScene& S, const double* d_dirs, const int32_t* d_pixels, int n_pixels, PrimaryHit* d_hits,

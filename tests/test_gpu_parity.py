@@ -30,21 +30,57 @@ def pair(request, oracle, mcpt):
     osc.close()
 
 
-def test_closest_hit_bit_exact(pair, oracle, mcpt):
+@pytest.mark.parametrize("mode", ["reference", "fast"])
+def test_closest_hit_bit_exact(pair, oracle, mcpt, mode):
     name, osc, sc, dev = pair
     rays = make_rays(osc, 40000, seed=11)
     of, ot, op, opn = osc.trace_closest(rays)
     st = mcpt.Stats()
-    gf, gt, gp, gpn = dev.ray_intersect(rays, stats=st)
+    dev.set_trace_mode(mcpt.TRACE_REFERENCE if mode == "reference" else mcpt.TRACE_FAST)
+    try:
+        gf, gt, gp, gpn = dev.ray_intersect(rays, stats=st)
+    finally:
+        dev.set_trace_mode(mcpt.TRACE_FAST)
     assert np.array_equal(of, gf), "closest-hit face index differs on %d rays" % int((of != gf).sum())
     hit = of >= 0
     assert hit.sum() > 1000
     assert np.array_equal(_bits(ot[hit]), _bits(gt[hit]))
     assert np.array_equal(_bits(op[hit]), _bits(gp[hit]))
     assert np.array_equal(_bits(opn[hit]), _bits(gpn[hit]))
-    ost = oracle.Stats()
-    osc.trace_closest(rays, stats=ost)
-    assert st.node_visits == ost.box_tests and st.tri_tests == ost.tri_tests
+    if mode == "reference":      # same walk -> same work
+        ost = oracle.Stats()
+        osc.trace_closest(rays, stats=ost)
+        assert st.node_visits == ost.box_tests and st.tri_tests == ost.tri_tests
+
+
+def test_fast_walk_equals_reference_walk_bulk(pair, mcpt):
+    """2 M rays, GPU against GPU: the accelerated walk must return the reference-shaped walk's answer bit for bit
+    (the latter is pinned to the oracle above).  Includes rays leaving surface points (the shadow/bounce pattern)."""
+    name, osc, sc, dev = pair
+    rng = np.random.default_rng(2024)
+    base = make_rays(osc, 200000, seed=3)
+    f0, t0, p0, _ = dev.ray_intersect(base)
+    hit = f0 >= 0
+    # secondary rays from hit points: random directions and grazing directions, origin offset like nextRay / shade
+    o = p0[hit]
+    n2 = o.shape[0]
+    d = rng.normal(size=(n2, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sec = np.hstack([o + 0.01 * d, d])
+    sec2 = np.hstack([o, d])                      # refraction rays start exactly on the surface
+    reps = []
+    for s_ in range(8):
+        reps.append(make_rays(osc, 200000, seed=100 + s_))
+    rays = np.vstack([base, sec, sec2] + reps)
+    dev.set_trace_mode(mcpt.TRACE_REFERENCE)
+    rf, rt, rp, rpn = dev.ray_intersect(rays)
+    dev.set_trace_mode(mcpt.TRACE_FAST)
+    st = mcpt.Stats()
+    ff, ft, fp, fpn = dev.ray_intersect(rays, stats=st)
+    assert np.array_equal(rf, ff), "%d of %d rays differ" % (int((rf != ff).sum()), rays.shape[0])
+    h = rf >= 0
+    assert np.array_equal(_bits(rt[h]), _bits(ft[h])) and np.array_equal(_bits(rp[h]), _bits(fp[h]))
+    assert np.array_equal(_bits(rpn[h]), _bits(fpn[h]))
 
 
 def test_sample_radiance(pair, oracle, mcpt):
