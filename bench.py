@@ -206,7 +206,7 @@ def main():
                        "primary_rays": "traced once per pixel (identical for every sample: the reference has no jitter)"},
             "rays_per_frame": rays / steps, "samples_per_frame": samples / steps,
             "nodes_per_ray": nodes / max(1.0, rays), "tris_per_ray": tris / max(1.0, rays),
-            "roofline": {"bound": "hbm", "kernel": "k_shade_samples", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_wf_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches": tot["launches"],
                          "algorithmic_bytes_per_launch": alg_bytes_rank0 / n_launch,

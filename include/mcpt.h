@@ -59,6 +59,8 @@ typedef struct {
     uint64_t rays_primary, rays_shadow, rays_bounce; /* closest-hit queries actually traced */
     uint64_t node_visits, tri_tests;                 /* box tests / triangle tests executed */
     uint64_t shade_calls, samples;
+    uint64_t shadow_skipped;                         /* shadow rays the reference traces although it never uses their answer
+                                                        (light behind the surface, pathTracing.cpp:217); not traced here */
     double   ms_trace, ms_total;                     /* device time of the dominant kernel / whole call (HIP events) */
     int32_t  launches;                               /* launches of the dominant kernel */
     int32_t  max_depth;
@@ -74,7 +76,8 @@ typedef struct {
 } mcpt_render_params;
 
 #define MCPT_RENDER_DEFAULT      0
-#define MCPT_RENDER_RETRACE_PRIMARY 1   /* re-trace the (identical) primary ray for every sample like the reference does */
+#define MCPT_RENDER_MEGAKERNEL   2   /* one lane per camera sample, whole path in one kernel, reference-shaped walk
+                                       (the first implementation; kept for A/B runs).  Default: wavefront pipeline. */
 
 /* ---- general ---- */
 int         mcpt_version(void);

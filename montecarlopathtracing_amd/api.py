@@ -9,6 +9,7 @@ from ._lib import McptError, RenderParams, RenderSceneOptions, SceneInfo, Stats,
 
 
 TRACE_FAST, TRACE_REFERENCE = 0, 1
+RENDER_DEFAULT, RENDER_MEGAKERNEL = 0, 2
 
 
 def _p(a, t):

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -14,6 +15,7 @@
 #include "accel_build.hpp"
 #include "kernels.hpp"
 #include "scene.hpp"
+#include "wavefront.hpp"
 
 using namespace mcpt;
 
@@ -37,6 +39,17 @@ int upload(const std::vector<T>& h, T** d)
     if (!h.empty()) HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return MCPT_OK;
 }
+template <class T>
+int grow(T** ptr, int64_t* cap, int64_t need)
+{
+    if (*cap >= need) return MCPT_OK;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(ptr), size_t(need) * sizeof(T)));
+    *cap = need;
+    return MCPT_OK;
+}
+
 }  // namespace
 
 struct mcpt_scene {
@@ -62,9 +75,12 @@ struct mcpt_device {
     PrimaryHit* hits = nullptr; int64_t hits_cap = 0;
     double* rad = nullptr; size_t rad_cap = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t sample_budget_bytes = size_t(4) << 30;   // radiance staging buffer (pixels x spp x 24 B per chunk)
-    Scene const* host = nullptr;           // not owned; used for the partition only (copied fields below)
-    int part_w = 0, part_h = 0;
+    size_t sample_budget_bytes = size_t(4) << 30;   // megakernel path: radiance staging buffer per chunk
+    // wavefront workspace
+    size_t wf_budget_bytes = size_t(40) << 30;      // path state + rays (MCPT_WORKSPACE_GB overrides)
+    void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
+    int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
+    WfCounts* wf_counts = nullptr;
 };
 
 extern "C" {
@@ -255,7 +271,7 @@ void mcpt_device_free(mcpt_device* d)
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
     void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris,
-                    d->dirs, d->ctr, d->pixels, d->hits, d->rad};
+                    d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->wf_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -355,6 +371,11 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
     if ((rc = upload(fb.nodes, &d->fast_nodes)) || (rc = upload(ftris, &d->fast_tris))) return rc;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->ctr), sizeof(DCounters)));
     HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->wf_counts), sizeof(WfCounts)));
+    if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
+        const double v = std::atof(gb);
+        if (v > 0.01) d->wf_budget_bytes = size_t(v * double(size_t(1) << 30));
+    }
 
     DScene& S = d->ds;
     S.nodes = d->nodes; S.tris = d->tris; S.shade = d->shade; S.materials = d->materials; S.lights = d->lights;
@@ -398,6 +419,7 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
 {
     s->rays_primary = c.rays_primary; s->rays_shadow = c.rays_shadow; s->rays_bounce = c.rays_bounce;
     s->node_visits = c.node_visits; s->tri_tests = c.tri_tests; s->shade_calls = c.shade_calls; s->samples = c.samples;
+    s->shadow_skipped = c.shadow_skipped;
     s->max_depth = int32_t(c.max_depth);
 }
 
@@ -472,41 +494,22 @@ static int prepare_partition(mcpt_device* d, const mcpt_render_params* p, hipStr
     return MCPT_OK;
 }
 
-int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, void* stream)
+// megakernel path: one lane per camera sample, the whole path in one kernel (kept for A/B runs and as a second
+// implementation the wavefront path is checked against)
+static int render_megakernel(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, hipStream_t st,
+                             double& ms_trace, int& launches)
 {
-    if (!d || !p || !d_img || p->spp <= 0) return fail(MCPT_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(d->ordinal));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (stats) std::memset(stats, 0, sizeof *stats);
-    int rc = ensure_dirs(d, st);
-    if (rc) return rc;
-    rc = prepare_partition(d, p, st);
-    if (rc) return rc;
     const int64_t npx = d->n_pixels;
-    if (npx == 0) return MCPT_OK;
-    if (d->hits_cap < npx) {
-        if (d->hits) (void)hipFree(d->hits);
-        d->hits = nullptr; d->hits_cap = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->hits), size_t(npx) * sizeof(PrimaryHit)));
-        d->hits_cap = npx;
-    }
     const int spp = p->spp;
     const size_t per_pixel = size_t(spp) * 3 * sizeof(double);
     int64_t chunk = int64_t(std::max<size_t>(d->sample_budget_bytes / per_pixel, 64));
     chunk = std::min<int64_t>(chunk, npx);
-    // keep n_slots*spp within int range of the kernels' index math (long long there, int slots here)
     if (d->rad_cap < size_t(chunk) * per_pixel) {
         if (d->rad) (void)hipFree(d->rad);
         d->rad = nullptr; d->rad_cap = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->rad), size_t(chunk) * per_pixel));
         d->rad_cap = size_t(chunk) * per_pixel;
     }
-    HIP_TRY(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), st));
-    HIP_TRY(hipEventRecord(d->ev[0], st));
-    launch_primary_hits(d->ds, d->dirs, d->pixels, int(npx), d->hits, d->ctr, st);
-    HIP_TRY(hipGetLastError());
-    double ms_trace = 0;
-    int launches = 0;
     for (int64_t first = 0; first < npx; first += chunk) {
         const int n_slots = int(std::min<int64_t>(chunk, npx - first));
         if (stats) HIP_TRY(hipEventRecord(d->ev[2], st));
@@ -520,9 +523,121 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
             ms_trace += ms;
         }
         launches++;
-        launch_fold_samples(d->rad, d->pixels, int(first), n_slots, spp, d_img, st);
+        launch_fold_samples(d->rad, d->pixels, d->hits, int(first), n_slots, spp, d_img, st);
         HIP_TRY(hipGetLastError());
     }
+    return MCPT_OK;
+}
+
+// wavefront path (wavefront.hpp): per chunk, lockstep iterations of logic + trace over compacted path state in HBM
+static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, hipStream_t st,
+                            double& ms_trace, int& launches)
+{
+    const int64_t npx = d->n_pixels;
+    const int spp = p->spp;
+    const int nl = d->ds.num_lights;
+    const bool fast = d->trace_mode == MCPT_TRACE_FAST;
+    const size_t bpp = wf_bytes_per_path(nl);
+    // chunk: as many pixels as the workspace budget holds paths for (every pixel may hit)
+    const size_t overhead = 64 * 1024;
+    int64_t cap = int64_t((d->wf_budget_bytes - overhead) / (bpp + 24));      // + 24 B radiance per sample
+    cap = std::min<int64_t>(cap, npx * int64_t(spp));
+    cap = std::min<int64_t>(cap, (int64_t(1) << 31) - 4096);                 // 32-bit compaction counter / sample ids
+    int64_t chunk_slots = std::max<int64_t>(cap / spp, 1);
+    chunk_slots = std::min<int64_t>(chunk_slots, npx);
+    cap = chunk_slots * spp;
+    const size_t ws_need = size_t(cap) * bpp + overhead;
+    if (d->wf_ws_bytes < ws_need) {
+        if (d->wf_ws) (void)hipFree(d->wf_ws);
+        d->wf_ws = nullptr; d->wf_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&d->wf_ws, ws_need));
+        d->wf_ws_bytes = ws_need;
+    }
+    const size_t rad_need = size_t(cap) * 3 * sizeof(double);
+    if (d->rad_cap < rad_need) {
+        if (d->rad) (void)hipFree(d->rad);
+        d->rad = nullptr; d->rad_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->rad), rad_need));
+        d->rad_cap = rad_need;
+    }
+    int rc = grow(&d->hit_slots, &d->hit_slots_cap, chunk_slots);
+    if (rc) return rc;
+    WfArgs a{};
+    WfState A, B;
+    if (!wf_carve(d->wf_ws, d->wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
+    a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = d->hit_slots; a.hits = d->hits;
+    a.dirs = d->dirs; a.rad = d->rad; a.counts = d->wf_counts; a.ctr = d->ctr;
+    bool pending = false;            // a timed trace launch whose events have not been read yet
+    auto read_pending = [&]() -> int {
+        if (pending) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev[2], d->ev[3]));
+            ms_trace += ms; pending = false;
+        }
+        return MCPT_OK;
+    };
+    for (int64_t first = 0; first < npx; first += chunk_slots) {
+        const int n_slots = int(std::min<int64_t>(chunk_slots, npx - first));
+        unsigned int n_hit = 0;
+        HIP_TRY(hipMemsetAsync(d->wf_counts, 0, sizeof(WfCounts), st));
+        launch_hit_slots(d->hits, int(first), n_slots, d->hit_slots, &d->wf_counts->n_next, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&n_hit, &d->wf_counts->n_next, sizeof n_hit, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = read_pending())) return rc;
+        long long n_prev = (long long)n_hit * spp;
+        a.first_slot = int(first);
+        a.in = A; a.out = B;
+        for (int depth = 0; n_prev > 0; depth++) {
+            a.depth = depth;
+            HIP_TRY(hipMemsetAsync(d->wf_counts, 0, sizeof(WfCounts), st));
+            launch_wf_logic(d->ds, a, n_prev, depth == 0, st);
+            HIP_TRY(hipGetLastError());
+            unsigned int n_next = 0;
+            HIP_TRY(hipMemcpyAsync(&n_next, &d->wf_counts->n_next, sizeof n_next, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if ((rc = read_pending())) return rc;
+            if (n_next == 0) break;
+            if (stats) HIP_TRY(hipEventRecord(d->ev[2], st));
+            launch_wf_trace(d->ds, a, n_next, fast, st);
+            HIP_TRY(hipGetLastError());
+            if (stats) { HIP_TRY(hipEventRecord(d->ev[3], st)); pending = true; }
+            launches++;
+            std::swap(a.in, a.out);
+            n_prev = n_next;
+        }
+        launch_fold_samples(d->rad, d->pixels, d->hits, int(first), n_slots, spp, d_img, st);
+        HIP_TRY(hipGetLastError());
+    }
+    if (pending) {
+        HIP_TRY(hipEventSynchronize(d->ev[3]));
+        if ((rc = read_pending())) return rc;
+    }
+    return MCPT_OK;
+}
+
+int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, void* stream)
+{
+    if (!d || !p || !d_img || p->spp <= 0) return fail(MCPT_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(d->ordinal));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    int rc = ensure_dirs(d, st);
+    if (rc) return rc;
+    rc = prepare_partition(d, p, st);
+    if (rc) return rc;
+    const int64_t npx = d->n_pixels;
+    if (npx == 0) return MCPT_OK;
+    if ((rc = grow(&d->hits, &d->hits_cap, npx))) return rc;
+    HIP_TRY(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), st));
+    HIP_TRY(hipEventRecord(d->ev[0], st));
+    launch_primary_hits(d->ds, d->trace_mode == MCPT_TRACE_FAST, d->dirs, d->pixels, int(npx), d->hits, d->ctr, st);
+    HIP_TRY(hipGetLastError());
+    double ms_trace = 0;
+    int launches = 0;
+    if (p->flags & MCPT_RENDER_MEGAKERNEL) rc = render_megakernel(d, p, d_img, stats, st, ms_trace, launches);
+    else rc = render_wavefront(d, p, d_img, stats, st, ms_trace, launches);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(d->ev[1], st));
     if (stats) {
         DCounters c{};
@@ -532,6 +647,7 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
         stats->ms_total = ms; stats->ms_trace = ms_trace; stats->launches = launches;
+        stats->samples = uint64_t(npx) * uint64_t(p->spp);      // camera samples covered (a primary miss is a finished sample)
     }
     return MCPT_OK;
 }

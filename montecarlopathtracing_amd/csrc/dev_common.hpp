@@ -192,12 +192,12 @@ __device__ __forceinline__ unsigned int wave_max(unsigned int v)
     for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_down(v, off, 64); v = o > v ? o : v; }
     return v;
 }
-struct LaneStats { uint32_t nodes = 0, tris = 0, shadow = 0, bounce = 0, primary = 0, shades = 0, samples = 0, depth = 0; };
+struct LaneStats { uint32_t nodes = 0, tris = 0, shadow = 0, bounce = 0, primary = 0, shades = 0, samples = 0, depth = 0, skipped = 0; };
 __device__ __forceinline__ void flush_stats(DCounters* c, const LaneStats& s)
 {
     if (!c) return;
     const unsigned long long n = wave_sum(s.nodes), t = wave_sum(s.tris), sh = wave_sum(s.shadow), bo = wave_sum(s.bounce),
-                             pr = wave_sum(s.primary), sc = wave_sum(s.shades), sa = wave_sum(s.samples);
+                             pr = wave_sum(s.primary), sc = wave_sum(s.shades), sa = wave_sum(s.samples), sk = wave_sum(s.skipped);
     const unsigned int md = wave_max(s.depth);
     if ((threadIdx.x & 63) == 0) {
         if (n) atomicAdd(&c->node_visits, n);
@@ -207,6 +207,7 @@ __device__ __forceinline__ void flush_stats(DCounters* c, const LaneStats& s)
         if (pr) atomicAdd(&c->rays_primary, pr);
         if (sc) atomicAdd(&c->shade_calls, sc);
         if (sa) atomicAdd(&c->samples, sa);
+        if (sk) atomicAdd(&c->shadow_skipped, sk);
         if (md) atomicMax(&c->max_depth, (unsigned long long)md);
     }
 }

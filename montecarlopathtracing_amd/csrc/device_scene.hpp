@@ -92,6 +92,8 @@ struct DScene {
 // device-side counters (one cache line)
 struct DCounters {
     unsigned long long rays_primary, rays_shadow, rays_bounce, node_visits, tri_tests, shade_calls, samples, max_depth;
+    unsigned long long shadow_skipped;   // shadow rays the reference traces although their result is never used (light behind the surface)
+    unsigned long long pad[7];
 };
 
 }  // namespace mcpt

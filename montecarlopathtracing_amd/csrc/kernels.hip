@@ -8,6 +8,7 @@
 
 #include "dev_common.hpp"
 #include "kernels.hpp"
+#include "shade_common.hpp"
 #include "trace_fast.hpp"
 
 namespace mcpt {
@@ -64,9 +65,11 @@ __global__ void k_primary_dirs(DCamera cam, double* __restrict__ dirs)
 
 // One lane per owned pixel: the primary ray is the same for every sample of a pixel (no jitter,
 // pathTracing.cpp:306-308), so it is traced once.
+template <bool FAST>
 __global__ void __launch_bounds__(256) k_primary_hits(DScene S, const double* __restrict__ dirs, const int32_t* __restrict__ pixels,
                                                       int n_pixels, PrimaryHit* __restrict__ hits, DCounters* ctr)
 {
+    __shared__ int lds_stack[FAST ? MCPT_FAST_STACK * 256 : 1];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     LaneStats ls;
     if (gid < n_pixels) {
@@ -74,55 +77,13 @@ __global__ void __launch_bounds__(256) k_primary_hits(DScene S, const double* __
         Ray r;
         r.o = ld3(S.cam.eye); r.d = ld3(dirs + (size_t)pix * 3);
         Hit h; Work w = {0, 0};
-        const bool ok = trace_closest(S, r, h, w);
+        const bool ok = trace_any<FAST>(S, r, h, w, lds_stack + threadIdx.x);
         ls.nodes = w.nodes; ls.tris = w.tris; ls.primary = 1;
         PrimaryHit ph;
         ph.leaf = ok ? h.leaf : -1; ph.pad = 0; ph.t = h.t; ph.p[0] = h.p.x; ph.p[1] = h.p.y; ph.p[2] = h.p.z;
         hits[gid] = ph;
     }
     flush_stats(ctr, ls);
-}
-
-// ---- shading pieces ------------------------------------------------------------------------------------------
-enum { RT_DIFFUSE = 0, RT_SPECULAR = 1, RT_TRANSMISSION = 2 };   // sceneManagement.h:203-205
-
-// Refract, pathTracing.cpp:13-27 (cosi and cost2 are floats in the reference)
-__device__ __forceinline__ bool refract_dir(V3 i, V3 n, double eta, V3& out)
-{
-    const float cosi = (float)dot(i, n);
-    const float cost2 = (float)(1.0f - eta * eta * (1.0f - cosi * cosi));
-    if (cost2 >= 0.0f) {
-        out = i * eta - n * (eta * cosi + sqrtf(cost2));
-        return true;
-    }
-    return false;
-}
-
-// BRDFImportanceSampling, pathTracing.cpp:30-64
-__device__ __forceinline__ V3 brdf_sample(double u_phi, double u_theta, V3 direction, int type, double Ns)
-{
-    const double phi = u_phi * 2 * MCPT_PI;
-    double theta;
-    if (type == RT_DIFFUSE) theta = asin(sqrt(u_theta));
-    else theta = acos(pow(u_theta, (double)1 / (Ns + 1)));
-    const V3 sample = mk(sin(theta) * cos(phi), cos(theta), sin(theta) * sin(phi));
-    V3 front;
-    if (fabs(direction.x) > fabs(direction.y)) front = normalized(mk(direction.z, 0, -direction.x));
-    else front = normalized(mk(0, -direction.z, direction.y));
-    const V3 right = cross(direction, front);
-    return normalized((right * sample.x + direction * sample.y) + front * sample.z);
-}
-
-// first j with rnd < cdf[j] (pathTracing.cpp:189-190), or -1
-__device__ __forceinline__ int pick_light_triangle(const double* __restrict__ cdf, int n, bool sorted, double rnd)
-{
-    if (sorted) {
-        int lo = 0, hi = n;                       // smallest j with rnd < cdf[j]
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rnd < cdf[mid]) hi = mid; else lo = mid + 1; }
-        return lo < n ? lo : -1;
-    }
-    for (int j = 0; j < n; j++) if (rnd < cdf[j]) return j;
-    return -1;
 }
 
 // shade() (pathTracing.cpp:137-266) with the recursion unrolled into a loop: the recursion is a chain
@@ -308,16 +269,17 @@ __global__ void __launch_bounds__(256) k_sample_radiance(DScene S, unsigned long
 
 // Per pixel: acc(float) += radiance/N for k = 0..N-1 in order (pathTracing.cpp:301,316-318 with D3), widened
 // to double for image::img (sceneManagement.h:221).  One lane per (pixel, channel).
-__global__ void k_fold_samples(const double* __restrict__ rad, const int32_t* __restrict__ pixels, int first_slot, int n_slots,
-                               int spp, double* __restrict__ img)
+__global__ void k_fold_samples(const double* __restrict__ rad, const int32_t* __restrict__ pixels, const PrimaryHit* __restrict__ hits,
+                               int first_slot, int n_slots, int spp, double* __restrict__ img)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)n_slots * 3) return;
     const int s = (int)(gid / 3), c = (int)(gid % 3);
     const double* src = rad + (size_t)s * spp * 3 + c;
-    float acc = 0.0f;
-    for (int k = 0; k < spp; k++) acc = (float)((double)acc + src[(size_t)k * 3] / spp);
     const int slot = first_slot + s;
+    float acc = 0.0f;
+    if (hits[slot].leaf >= 0)            // a primary miss adds nothing (pathTracing.cpp:311)
+        for (int k = 0; k < spp; k++) acc = (float)((double)acc + src[(size_t)k * 3] / spp);
     const int pix = pixels ? pixels[slot] : slot;
     img[(size_t)pix * 3 + c] = (double)acc;
 }
@@ -336,11 +298,12 @@ void launch_primary_dirs(const DCamera& cam, double* d_dirs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_primary_dirs, dim3(blocks_for(cam.height, 64)), dim3(64), 0, st, cam, d_dirs);
 }
-void launch_primary_hits(const DScene& S, const double* d_dirs, const int32_t* d_pixels, int n_pixels, PrimaryHit* d_hits,
+void launch_primary_hits(const DScene& S, bool fast, const double* d_dirs, const int32_t* d_pixels, int n_pixels, PrimaryHit* d_hits,
                          DCounters* ctr, hipStream_t st)
 {
     if (n_pixels <= 0) return;
-    hipLaunchKernelGGL(k_primary_hits, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, st, S, d_dirs, d_pixels, n_pixels, d_hits, ctr);
+    if (fast) hipLaunchKernelGGL(k_primary_hits<true>, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, st, S, d_dirs, d_pixels, n_pixels, d_hits, ctr);
+    else hipLaunchKernelGGL(k_primary_hits<false>, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, st, S, d_dirs, d_pixels, n_pixels, d_hits, ctr);
 }
 void launch_shade_samples(const DScene& S, unsigned long long seed, const double* d_dirs, const int32_t* d_pixels,
                           const PrimaryHit* d_hits, int first_slot, int n_slots, int spp, double* d_rad, DCounters* ctr, hipStream_t st)
@@ -355,10 +318,11 @@ void launch_sample_radiance(const DScene& S, unsigned long long seed, const doub
     if (n <= 0) return;
     hipLaunchKernelGGL(k_sample_radiance, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, seed, d_dirs, d_pix, d_k, n, d_rgb, ctr);
 }
-void launch_fold_samples(const double* d_rad, const int32_t* d_pixels, int first_slot, int n_slots, int spp, double* d_img, hipStream_t st)
+void launch_fold_samples(const double* d_rad, const int32_t* d_pixels, const PrimaryHit* d_hits, int first_slot, int n_slots, int spp,
+                         double* d_img, hipStream_t st)
 {
     if (n_slots <= 0) return;
-    hipLaunchKernelGGL(k_fold_samples, dim3(blocks_for((long long)n_slots * 3, 256)), dim3(256), 0, st, d_rad, d_pixels, first_slot, n_slots, spp, d_img);
+    hipLaunchKernelGGL(k_fold_samples, dim3(blocks_for((long long)n_slots * 3, 256)), dim3(256), 0, st, d_rad, d_pixels, d_hits, first_slot, n_slots, spp, d_img);
 }
 
 }  // namespace mcpt

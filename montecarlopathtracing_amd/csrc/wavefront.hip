@@ -1,0 +1,341 @@
+// Wavefront integrator kernels (see wavefront.hpp).  -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "dev_common.hpp"
+#include "shade_common.hpp"
+#include "trace_fast.hpp"
+#include "wavefront.hpp"
+
+namespace mcpt {
+
+// ---------------------------------------------------------------------------------------------- layout helpers
+__device__ __forceinline__ V3 ldc(const double* __restrict__ a, long long cap, long long i)
+{
+    return mk(a[i], a[cap + i], a[2 * cap + i]);
+}
+__device__ __forceinline__ void stc(double* __restrict__ a, long long cap, long long i, V3 v)
+{
+    a[i] = v.x; a[cap + i] = v.y; a[2 * cap + i] = v.z;
+}
+
+size_t wf_bytes_per_path(int nl)
+{
+    const size_t state = 4 + (6 + 3 * nl + 6) * 8 + nl * 4 + 4 + nl * 4 + 4 + 3 * 8;   // WfState
+    const size_t rays = (nl + 1) * 6 * 8;                                            // WfRays
+    return 2 * state + rays;
+}
+
+bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfState& B, WfRays& R)
+{
+    char* p = static_cast<char*>(base);
+    char* end = p + bytes;
+    auto take = [&](size_t n) -> void* { char* r = p; p += (n + 255) & ~size_t(255); return r; };
+    auto state = [&](WfState& s) {
+        s.id = static_cast<int32_t*>(take(cap * 4));
+        s.T = static_cast<double*>(take(cap * 24)); s.L = static_cast<double*>(take(cap * 24));
+        s.c = static_cast<double*>(take(size_t(cap) * 24 * nl)); s.expect = static_cast<int32_t*>(take(size_t(cap) * 4 * nl));
+        s.w = static_cast<double*>(take(cap * 24)); s.bdir = static_cast<double*>(take(cap * 24));
+        s.btype = static_cast<int32_t*>(take(cap * 4));
+        s.hit_mat = static_cast<int32_t*>(take(size_t(cap) * 4 * nl)); s.hit_leaf = static_cast<int32_t*>(take(cap * 4));
+        s.hit_p = static_cast<double*>(take(cap * 24));
+    };
+    state(A); state(B);
+    R.o = static_cast<double*>(take(size_t(cap) * 24 * (nl + 1))); R.d = static_cast<double*>(take(size_t(cap) * 24 * (nl + 1)));
+    return p <= end;
+}
+
+// ---------------------------------------------------------------------------------------------- logic kernel
+// One thread per path position of the previous iteration.  FIRST: positions enumerate (hit slot, k).
+template <bool FIRST>
+__global__ void __launch_bounds__(256) k_wf_logic(DScene S, WfArgs a, long long n_prev)
+{
+    __shared__ unsigned int wave_tot[4];
+    __shared__ unsigned int block_base;
+    const long long cap = a.cap;
+    const int nl = a.nl;
+    const uint32_t depth = (uint32_t)a.depth;           // depth of the vertex shaded in this pass
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    LaneStats ls;
+    const long long n_round = (n_prev + 255) / 256 * 256;
+    for (long long base = (long long)blockIdx.x * 256; base < n_round; base += (long long)gridDim.x * 256) {
+        const long long i = base + threadIdx.x;
+        bool alive = false;
+        int id = 0, leaf = -1, in_type = RT_TRANSMISSION;
+        V3 p = mk(0, 0, 0), dir = mk(0, 0, 0), T = mk(1, 1, 1), L = mk(0, 0, 0);
+        if (i < n_prev) {
+            bool have_vertex;
+            if constexpr (FIRST) {
+                const int slot = a.hit_slots[i / a.spp];
+                const int k = (int)(i % a.spp);
+                id = (slot - a.first_slot) * a.spp + k;
+                const PrimaryHit ph = a.hits[slot];
+                const int pix = a.pixels ? a.pixels[slot] : slot;
+                leaf = ph.leaf; p = mk(ph.p[0], ph.p[1], ph.p[2]);
+                dir = neg(ld3(a.dirs + (size_t)pix * 3));
+                have_vertex = true;
+                ls.samples = 1;
+            } else {
+                // ---- resolve vertex depth-1 (pathTracing.cpp:213-231, 244-261)
+                id = a.in.id[i];
+                T = ldc(a.in.T, cap, i); L = ldc(a.in.L, cap, i);
+                V3 L_dir = mk(0, 0, 0);
+                for (int l = 0; l < nl; l++) {
+                    const int expect = a.in.expect[(long long)l * cap + i];
+                    if (expect == -2) continue;
+                    const V3 c = ldc(a.in.c + (long long)l * 3 * cap, cap, i);
+                    const bool vis = a.in.hit_mat[(long long)l * cap + i] == expect;
+                    L_dir.x += vis ? c.x : c.x * 0.0;
+                    L_dir.y += vis ? c.y : c.y * 0.0;
+                    L_dir.z += vis ? c.z : c.z * 0.0;
+                }
+                L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
+                const int bt = a.in.btype[i];
+                have_vertex = false;
+                if (bt >= 0) {
+                    const int hl = a.in.hit_leaf[i];
+                    if (hl >= 0) {
+                        const V3 wgt = ldc(a.in.w, cap, i);
+                        T = mk(T.x * wgt.x / MCPT_P_RR, T.y * wgt.y / MCPT_P_RR, T.z * wgt.z / MCPT_P_RR);
+                        leaf = hl; p = ldc(a.in.hit_p, cap, i);
+                        dir = neg(ldc(a.in.bdir, cap, i));
+                        in_type = bt;
+                        have_vertex = true;
+                    }
+                }
+            }
+            if (have_vertex) {
+                ls.shades++;
+                if (depth > ls.depth) ls.depth = depth;
+                const DMaterial* m = S.materials + S.tris[leaf].material;
+                if (m->light >= 0) {                                             // emitter: pathTracing.cpp:141-144
+                    const V3 rad = ld3(S.lights[m->light].radiance);
+                    if (FIRST) L = rad;
+                    else if (in_type != RT_DIFFUSE) L = L + mk(T.x * rad.x, T.y * rad.y, T.z * rad.z);
+                } else alive = true;
+            }
+            if (!alive) { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; }
+        }
+        // ---- compaction: wave ballot + prefix, one atomic per block
+        const unsigned long long bal = __ballot(alive);
+        const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = (unsigned int)__popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            block_base = tot ? atomicAdd(&a.counts->n_next, tot) : 0u;
+        }
+        __syncthreads();
+        unsigned int off = block_base + before;
+        for (int q = 0; q < wv; q++) off += wave_tot[q];
+        __syncthreads();
+        if (!alive) continue;
+        const long long j = off;
+
+        // ---- shade vertex `depth` at position j (pathTracing.cpp:147-241)
+        const DTri* tr = S.tris + leaf;
+        const DMaterial* m = S.materials + tr->material;
+        const DTriShade* sh = S.shade + leaf;
+        const V3 g = barycentric(ld3(tr->v1), ld3(tr->v2), ld3(tr->v3), p);
+        const V3 pn = (ld3(sh->vn1) * g.x + ld3(sh->vn2) * g.y) + ld3(sh->vn3) * g.z;
+        V3 kd;
+        if (m->has_map) {
+            const double row = sh->vt1[0] * g.x + sh->vt2[0] * g.y + sh->vt3[0] * g.z;
+            const double col = sh->vt1[1] * g.x + sh->vt2[1] * g.y + sh->vt3[1] * g.z;
+            const double irow = row - floor(row), icol = col - floor(col);
+            int rr = (int)(irow * m->map_h), cc = (int)(icol * m->map_w);
+            rr = rr < 0 ? 0 : (rr > m->map_h - 1 ? m->map_h - 1 : rr);
+            cc = cc < 0 ? 0 : (cc > m->map_w - 1 ? m->map_w - 1 : cc);
+            const uint8_t* px = S.texels + m->tex_offset + ((size_t)rr * m->map_w + cc) * 3;
+            kd = mk((double)px[2] / 255, (double)px[1] / 255, (double)px[0] / 255);
+        } else kd = ld3(m->kd);
+
+        const int slot = a.first_slot + id / a.spp;
+        RngKey key;
+        key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
+        key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); key.sample = (uint32_t)(id % a.spp);
+
+        int sample_mat = -1;
+        for (int l = 0; l < nl; l++) {
+            const DLight* lt = S.lights + l;
+            V3 xl = mk(0, 0, 0), vn = mk(0, 0, 0);
+            double u0, u1, u2, u3;
+            uniform2(key, depth, 2u * l, u0, u1);
+            const double rnd = u0 * S.area0;
+            const int jt = pick_light_triangle(S.light_cdf + lt->first, lt->ntri, lt->cdf_sorted != 0, rnd);
+            if (jt >= 0) {
+                uniform2(key, depth, 2u * l + 1u, u2, u3);
+                const DLightTri* q = S.light_tris + lt->first + jt;
+                sample_mat = lt->material;
+                const double p1 = u1 / (u1 + u2 + u3), p2 = u2 / (u1 + u2 + u3), p3 = u3 / (u1 + u2 + u3);
+                xl = (ld3(q->v1) * p1 + ld3(q->v2) * p2) + ld3(q->v3) * p3;
+                vn = (ld3(q->vn1) * p1 + ld3(q->vn2) * p2) + ld3(q->vn3) * p3;
+            }
+            const V3 direction = normalized(xl - p);
+            const double kd_dots = dot(direction, pn);
+            int expect = -2;
+            if (kd_dots > 0) {                                                   // the only case in which the shadow ray's answer is used
+                const double pdf_light = (double)1 / lt->total_area;
+                const double cos_theta = fabs(dot(direction, vn) / norm(direction) / norm(vn));
+                const double cos_theta_hat = fabs(dot(direction, pn) / norm(direction) / norm(pn));
+                const double dd = norm(xl - p);
+                const double dist = (1.0 < dd) ? dd : 1.0;
+                const V3 intensity = ((((ld3(lt->radiance) * cos_theta) * cos_theta_hat) / pow(dist, 2.0)) / pdf_light) * 1.0;
+                const V3 c = mk(kd.x * intensity.x * kd_dots / MCPT_PI, kd.y * intensity.y * kd_dots / MCPT_PI, kd.z * intensity.z * kd_dots / MCPT_PI);
+                stc(a.out.c + (long long)l * 3 * cap, cap, j, c);
+                stc(a.rays.o + (long long)l * 3 * cap, cap, j, p + direction * 0.01);
+                stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);
+                expect = sample_mat;
+                ls.shadow++;
+            } else ls.skipped++;
+            a.out.expect[(long long)l * cap + j] = expect;
+        }
+
+        int btype = -1;
+        V3 wgt = mk(1, 1, 1);
+        if (depth + 1 < MCPT_MAX_DEPTH_DEV) {
+            double u_rr, u_fresnel;
+            uniform2(key, depth, 2u * nl, u_rr, u_fresnel);
+            if (u_rr < MCPT_P_RR) {
+                Ray nr;
+                const V3 ks = ld3(m->ks);
+                if (m->Ni > 1) {
+                    double n1, n2;
+                    const double cos_in = dot(neg(dir), pn);
+                    V3 normal;
+                    if (cos_in > 0) { normal = neg(pn); n1 = m->Ni; n2 = 1.0; }
+                    else { normal = pn; n1 = 1.0; n2 = m->Ni; }
+                    const double rf0 = pow((n1 - n2) / (n1 + n2), 2.0);
+                    const double fresnel = rf0 + (1.0f - rf0) * pow(1.0f - fabs(cos_in), 5.0);
+                    if (fresnel < u_fresnel) {
+                        V3 direction;
+                        if (refract_dir(neg(dir), normal, n1 / n2, direction)) { nr.o = p; nr.d = direction; btype = RT_TRANSMISSION; }
+                        else {
+                            const V3 incoming = neg(dir);
+                            nr.o = p; nr.d = incoming - (normal * dot(incoming, normal)) * 2; btype = RT_SPECULAR;
+                        }
+                    }
+                }
+                if (btype < 0) {
+                    double u_lobe, u_phi, u_theta, unused;
+                    uniform2(key, depth, 2u * nl + 1u, u_lobe, u_phi);
+                    uniform2(key, depth, 2u * nl + 2u, u_theta, unused);
+                    const double kd_norm = norm(kd), ks_norm = norm(ks);
+                    V3 direction;
+                    if (ks_norm != 0 && kd_norm / ks_norm < u_lobe) {
+                        const V3 incoming = neg(dir);
+                        const V3 reflect = incoming - (pn * dot(incoming, pn)) * 2;
+                        direction = brdf_sample(u_phi, u_theta, reflect, RT_SPECULAR, m->Ns);
+                        btype = RT_SPECULAR;
+                    } else {
+                        direction = brdf_sample(u_phi, u_theta, pn, RT_DIFFUSE, m->Ns);
+                        btype = RT_DIFFUSE;
+                    }
+                    nr.o = p + direction * 0.01; nr.d = direction;
+                }
+                wgt = btype == RT_DIFFUSE ? kd : (btype == RT_SPECULAR ? ks : mk(1, 1, 1));
+                stc(a.rays.o + (long long)nl * 3 * cap, cap, j, nr.o);
+                stc(a.rays.d + (long long)nl * 3 * cap, cap, j, nr.d);
+                stc(a.out.bdir, cap, j, nr.d);
+                ls.bounce++;
+            }
+        }
+        a.out.id[j] = id;
+        a.out.btype[j] = btype;
+        stc(a.out.w, cap, j, wgt);
+        stc(a.out.T, cap, j, T);
+        stc(a.out.L, cap, j, L);
+    }
+    flush_stats(a.ctr, ls);
+}
+
+// ---------------------------------------------------------------------------------------------- trace kernel
+// One thread per ray slot q = l*n_paths + j, l in [0, nl] (l == nl: the bounce ray).
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfArgs a, long long n_paths)
+{
+    __shared__ int lds_stack[FAST ? MCPT_FAST_STACK * 256 : 1];
+    const long long cap = a.cap;
+    const int nl = a.nl;
+    const long long total = n_paths * (nl + 1);
+    LaneStats ls;
+    Work w = {0, 0};
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const int l = (int)(q / n_paths);
+        const long long j = q - (long long)l * n_paths;
+        const bool is_bounce = l == nl;
+        const bool valid = is_bounce ? a.out.btype[j] >= 0 : a.out.expect[(long long)l * cap + j] != -2;
+        if (!valid) continue;
+        Ray r;
+        r.o = ldc(a.rays.o + (long long)l * 3 * cap, cap, j);
+        r.d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j);
+        Hit h;
+        bool ok;
+        if constexpr (FAST) ok = trace_closest_fast(S, r, h, w, lds_stack + threadIdx.x, 256);
+        else ok = trace_closest(S, r, h, w);
+        if (is_bounce) {
+            a.out.hit_leaf[j] = ok ? h.leaf : -1;
+            if (ok) stc(a.out.hit_p, cap, j, h.p);
+        } else {
+            a.out.hit_mat[(long long)l * cap + j] = ok ? S.tris[h.leaf].material : -1;
+        }
+    }
+    ls.nodes = w.nodes; ls.tris = w.tris;
+    flush_stats(a.ctr, ls);
+}
+
+// slots of this chunk whose primary ray hit something, in slot order within a wave
+__global__ void k_hit_slots(const PrimaryHit* __restrict__ hits, int first_slot, int n_slots, int32_t* __restrict__ hit_slots, unsigned int* count)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool hit = s < n_slots && hits[first_slot + s].leaf >= 0;
+    const unsigned long long bal = __ballot(hit);
+    const int lane = threadIdx.x & 63;
+    unsigned int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(count, (unsigned int)__popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (hit) hit_slots[base + __popcll(bal & ((1ull << lane) - 1ull))] = first_slot + s;
+}
+
+__global__ void k_zero(double* __restrict__ p, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+static unsigned grid_for(long long n, int block, unsigned cap_blocks)
+{
+    long long b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap_blocks ? cap_blocks : b);
+}
+
+void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_prev, bool first, hipStream_t st)
+{
+    if (n_prev <= 0) return;
+    const unsigned g = grid_for(n_prev, 256, 256u * 64u);
+    if (first) hipLaunchKernelGGL(k_wf_logic<true>, dim3(g), dim3(256), 0, st, S, a, n_prev);
+    else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a, n_prev);
+}
+
+void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, hipStream_t st)
+{
+    if (n_paths <= 0) return;
+    const long long total = n_paths * (a.nl + 1);
+    const unsigned g = grid_for(total, 256, 1u << 30);
+    if (fast) hipLaunchKernelGGL(k_wf_trace<true>, dim3(g), dim3(256), 0, st, S, a, n_paths);
+    else hipLaunchKernelGGL(k_wf_trace<false>, dim3(g), dim3(256), 0, st, S, a, n_paths);
+}
+
+void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)
+{
+    if (n_slots <= 0) return;
+    hipLaunchKernelGGL(k_hit_slots, dim3((n_slots + 255) / 256), dim3(256), 0, st, hits, first_slot, n_slots, hit_slots, count);
+}
+
+void launch_zero_rad(double* rad, long long n, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_zero, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, rad, n);
+}
+
+}  // namespace mcpt

@@ -1,0 +1,69 @@
+// Wavefront formulation of generateImg's sample loop (pathTracing.cpp:303-320) for one chunk of camera samples.
+//
+// All paths of a chunk advance in lockstep, one path vertex per iteration:
+//     logic(d):  resolve the rays of vertex d-1 (visibility -> direct light, bounce hit -> next vertex),
+//                shade vertex d (emitter test, texture, light sampling, Russian roulette, BSDF sample),
+//                emit its shadow rays and its bounce ray, compact the surviving paths (wave ballot + prefix).
+//     trace(d):  closest hit of every emitted ray (the dominant kernel; fast walk of trace_fast.hpp).
+// Path state lives in HBM as component-major SoA indexed by the compacted position, so every load/store of a wave
+// is one contiguous 512-byte run.  Two copies (A/B) because compaction moves paths between iterations.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "device_scene.hpp"
+#include "kernels.hpp"
+
+namespace mcpt {
+
+struct WfState {            // one side of the double buffer; every array has `cap` entries per component
+    int32_t* id;            // chunk-local sample id = (slot - first_slot) * spp + k
+    double* T;              // [3][cap] throughput at the vertex that was just shaded
+    double* L;              // [3][cap] radiance gathered before that vertex
+    // what shade(d) leaves for resolve(d):
+    double* c;              // [nl][3][cap] direct-light contribution of light l if visible
+    int32_t* expect;        // [nl][cap] material the shadow ray must hit to be visible; -2 = no shadow ray
+    double* w;              // [3][cap] weight of the bounce (kd / ks / 1)
+    double* bdir;           // [3][cap] direction of the bounce ray
+    int32_t* btype;         // [cap] ray_type of the bounce ray, -1 = none
+    // what trace(d) adds:
+    int32_t* hit_mat;       // [nl][cap] material of the shadow ray's closest hit, -1 = miss
+    int32_t* hit_leaf;      // [cap]     bounce ray: leaf or -1
+    double* hit_p;          // [3][cap]  bounce ray: hit point
+};
+
+struct WfRays {             // written by logic(d), consumed by trace(d); slot (l, j), l = nl for the bounce ray
+    double* o;              // [nl+1][3][cap]
+    double* d;              // [nl+1][3][cap]
+};
+
+struct WfCounts {           // device-side counters of one iteration
+    unsigned int n_next;    // paths alive after compaction
+    unsigned int pad[15];
+};
+
+struct WfArgs {
+    WfState in, out;
+    WfRays rays;
+    long long cap;
+    int nl, spp, depth;
+    unsigned long long seed;
+    const int32_t* pixels;      // slot -> pixel index (NULL: identity)
+    const int32_t* hit_slots;   // first pass: compacted list of slots whose primary ray hit something
+    const PrimaryHit* hits;     // first pass: primary hit per slot
+    const double* dirs;         // primary directions per pixel
+    int first_slot;
+    double* rad;                // [chunk samples][3] finished radiance
+    WfCounts* counts;           // counts[0] = this iteration's output
+    DCounters* ctr;
+};
+
+size_t wf_bytes_per_path(int nl);
+// carve the workspace; returns false if it does not fit
+bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& a, WfState& b, WfRays& r);
+
+void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_prev, bool first, hipStream_t st);
+void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, hipStream_t st);
+void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st);
+void launch_zero_rad(double* rad, long long n_doubles, hipStream_t st);
+
+}  // namespace mcpt

@@ -98,22 +98,32 @@ def test_sample_radiance(pair, oracle, mcpt):
     assert np.abs(o).sum() > 0
 
 
-def test_image_matches_oracle(pair, oracle, mcpt):
+@pytest.mark.parametrize("pipeline", ["wavefront", "megakernel"])
+def test_image_matches_oracle(pair, oracle, mcpt, pipeline):
     name, osc, sc, dev = pair
     spp = 8
     ost = oracle.Stats()
     ref = osc.render(spp, seed=3, stats=ost)
     st = mcpt.Stats()
-    img = dev.generateImg(spp, seed=3, stats=st)
+    img = dev.generateImg(spp, seed=3, stats=st, flags=mcpt.RENDER_MEGAKERNEL if pipeline == "megakernel" else 0)
     assert img.shape == ref.shape
     scale = np.maximum(np.abs(ref), 1e-6)
     rel = np.abs(img - ref) / scale
     bad = int((rel > 1e-6).sum())      # float accumulator: 1 ulp of fp32 ~ 6e-8
     assert bad <= max(3, img.size // 20000), "%d pixel channels differ (max rel %.3e)" % (bad, rel.max())
     # same work was done
-    assert st.rays_shadow == ost.rays_shadow and st.rays_bounce == ost.rays_bounce
+    assert st.rays_shadow + st.shadow_skipped == ost.rays_shadow and st.rays_bounce == ost.rays_bounce
+    assert st.shade_calls == ost.shade_calls and st.samples == ost.samples
     assert np.array_equal(mcpt.imshow_rgb8(img) != oracle.quantize(ref), np.zeros_like(img, dtype=bool)) or \
         int((mcpt.imshow_rgb8(img) != oracle.quantize(ref)).sum()) <= 8
+
+
+def test_pipelines_agree_bitwise(pair, mcpt):
+    """wavefront + fast walk vs megakernel + reference walk: same arithmetic per sample, so the same bits."""
+    name, osc, sc, dev = pair
+    a = dev.generateImg(16, seed=21)
+    b = dev.generateImg(16, seed=21, flags=mcpt.RENDER_MEGAKERNEL)
+    assert np.array_equal(_bits(a), _bits(b)), "%d channels differ" % int((_bits(a) != _bits(b)).sum())
 
 
 def test_partition_independent(pair, mcpt):
