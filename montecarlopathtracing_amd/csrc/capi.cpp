@@ -81,6 +81,9 @@ struct mcpt_device {
     void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
     int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
     WfCounts* wf_counts = nullptr;
+    TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
+    long long* slow_list = nullptr;
+    unsigned int slow_cap = 1u << 20;
 };
 
 extern "C" {
@@ -271,7 +274,7 @@ void mcpt_device_free(mcpt_device* d)
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
     void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris,
-                    d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->wf_counts};
+                    d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->wf_counts, d->queue, d->slow_list};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -372,6 +375,8 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->ctr), sizeof(DCounters)));
     HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->wf_counts), sizeof(WfCounts)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->queue), sizeof(TraceQueue)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->slow_list), size_t(d->slow_cap) * sizeof(long long)));
     if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
         const double v = std::atof(gb);
         if (v > 0.01) d->wf_budget_bytes = size_t(v * double(size_t(1) << 30));
@@ -566,7 +571,7 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
     WfState A, B;
     if (!wf_carve(d->wf_ws, d->wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
     a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = d->hit_slots; a.hits = d->hits;
-    a.dirs = d->dirs; a.rad = d->rad; a.counts = d->wf_counts; a.ctr = d->ctr;
+    a.dirs = d->dirs; a.rad = d->rad; a.counts = d->wf_counts; a.ctr = d->ctr; a.tris = d->tris;
     bool pending = false;            // a timed trace launch whose events have not been read yet
     auto read_pending = [&]() -> int {
         if (pending) {
@@ -599,7 +604,7 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
             if ((rc = read_pending())) return rc;
             if (n_next == 0) break;
             if (stats) HIP_TRY(hipEventRecord(d->ev[2], st));
-            launch_wf_trace(d->ds, a, n_next, fast, st);
+            launch_wf_trace(d->ds, a, n_next, fast, d->queue, d->slow_list, d->slow_cap, st);
             HIP_TRY(hipGetLastError());
             if (stats) { HIP_TRY(hipEventRecord(d->ev[3], st)); pending = true; }
             launches++;

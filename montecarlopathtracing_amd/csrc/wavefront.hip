@@ -3,7 +3,7 @@
 
 #include "dev_common.hpp"
 #include "shade_common.hpp"
-#include "trace_fast.hpp"
+#include "trace_persistent.hpp"
 #include "wavefront.hpp"
 
 namespace mcpt {
@@ -248,36 +248,72 @@ __global__ void __launch_bounds__(256) k_wf_logic(DScene S, WfArgs a, long long 
     flush_stats(a.ctr, ls);
 }
 
-// ---------------------------------------------------------------------------------------------- trace kernel
-// One thread per ray slot q = l*n_paths + j, l in [0, nl] (l == nl: the bounce ray).
-template <bool FAST>
-__global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfArgs a, long long n_paths)
+// ---------------------------------------------------------------------------------------------- trace kernels
+// ray slot q = l*n_paths + j, l in [0, nl] (l == nl: the bounce ray of path j)
+struct WfRaySource {
+    WfArgs a;
+    long long n_paths;
+    __device__ __forceinline__ long long total() const { return n_paths * (a.nl + 1); }
+    __device__ __forceinline__ bool fetch(long long q, Ray& r) const
+    {
+        const int l = (int)(q / n_paths);
+        const long long j = q - (long long)l * n_paths;
+        const bool valid = l == a.nl ? a.out.btype[j] >= 0 : a.out.expect[(long long)l * a.cap + j] != -2;
+        if (!valid) return false;
+        r.o = ldc(a.rays.o + (long long)l * 3 * a.cap, a.cap, j);
+        r.d = ldc(a.rays.d + (long long)l * 3 * a.cap, a.cap, j);
+        return true;
+    }
+    __device__ __forceinline__ void store(long long q, bool ok, const Hit& h) const
+    {
+        const int l = (int)(q / n_paths);
+        const long long j = q - (long long)l * n_paths;
+        if (l == a.nl) {
+            a.out.hit_leaf[j] = ok ? h.leaf : -1;
+            if (ok) stc(a.out.hit_p, a.cap, j, h.p);
+        } else {
+            a.out.hit_mat[(long long)l * a.cap + j] = ok ? a.tris[h.leaf].material : -1;
+        }
+    }
+};
+
+// persistent fast walk
+__global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfArgs a, long long n_paths, TraceQueue* queue, long long* slow_list,
+                                                  unsigned int slow_cap, long long chunk)
 {
-    __shared__ int lds_stack[FAST ? MCPT_FAST_STACK * 256 : 1];
-    const long long cap = a.cap;
-    const int nl = a.nl;
-    const long long total = n_paths * (nl + 1);
+    __shared__ int lds_stack[MCPT_FAST_STACK * 256];
+    WfRaySource src; src.a = a; src.n_paths = n_paths;
+    LaneStats ls;
+    Work w = {0, 0};
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, w);
+    ls.nodes = w.nodes; ls.tris = w.tris;
+    flush_stats(a.ctr, ls);
+}
+
+__global__ void __launch_bounds__(256) k_wf_trace_slow(DScene S, WfArgs a, long long n_paths, const TraceQueue* queue, const long long* slow_list,
+                                                       unsigned int slow_cap)
+{
+    WfRaySource src; src.a = a; src.n_paths = n_paths;
+    LaneStats ls;
+    Work w = {0, 0};
+    trace_slow_list(S, src, queue, slow_list, slow_cap, w);
+    ls.nodes = w.nodes; ls.tris = w.tris;
+    flush_stats(a.ctr, ls);
+}
+
+// reference-shaped walk for every ray (MCPT_TRACE_REFERENCE): one thread per slot
+__global__ void __launch_bounds__(256) k_wf_trace_reference(DScene S, WfArgs a, long long n_paths)
+{
+    WfRaySource src; src.a = a; src.n_paths = n_paths;
+    const long long total = src.total();
     LaneStats ls;
     Work w = {0, 0};
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
-        const int l = (int)(q / n_paths);
-        const long long j = q - (long long)l * n_paths;
-        const bool is_bounce = l == nl;
-        const bool valid = is_bounce ? a.out.btype[j] >= 0 : a.out.expect[(long long)l * cap + j] != -2;
-        if (!valid) continue;
         Ray r;
-        r.o = ldc(a.rays.o + (long long)l * 3 * cap, cap, j);
-        r.d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j);
+        if (!src.fetch(q, r)) continue;
         Hit h;
-        bool ok;
-        if constexpr (FAST) ok = trace_closest_fast(S, r, h, w, lds_stack + threadIdx.x, 256);
-        else ok = trace_closest(S, r, h, w);
-        if (is_bounce) {
-            a.out.hit_leaf[j] = ok ? h.leaf : -1;
-            if (ok) stc(a.out.hit_p, cap, j, h.p);
-        } else {
-            a.out.hit_mat[(long long)l * cap + j] = ok ? S.tris[h.leaf].material : -1;
-        }
+        const bool ok = trace_closest(S, r, h, w);
+        src.store(q, ok, h);
     }
     ls.nodes = w.nodes; ls.tris = w.tris;
     flush_stats(a.ctr, ls);
@@ -317,13 +353,46 @@ void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_prev, bool fi
     else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a, n_prev);
 }
 
-void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, hipStream_t st)
+int persistent_grid(const void* kernel)
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    return cus * per_cu;
+}
+
+long long persistent_chunk(long long total, int grid_blocks)
+{
+    const long long waves = (long long)grid_blocks * 4;
+    long long c = total / (waves * 4);
+    c = (c / 64) * 64;
+    if (c < 64) c = 64;
+    if (c > 2048) c = 2048;
+    return c;
+}
+
+void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, TraceQueue* queue, long long* slow_list,
+                     unsigned int slow_cap, hipStream_t st)
 {
     if (n_paths <= 0) return;
     const long long total = n_paths * (a.nl + 1);
-    const unsigned g = grid_for(total, 256, 1u << 30);
-    if (fast) hipLaunchKernelGGL(k_wf_trace<true>, dim3(g), dim3(256), 0, st, S, a, n_paths);
-    else hipLaunchKernelGGL(k_wf_trace<false>, dim3(g), dim3(256), 0, st, S, a, n_paths);
+    if (!fast) {
+        hipLaunchKernelGGL(k_wf_trace_reference, dim3(grid_for(total, 256, 1u << 30)), dim3(256), 0, st, S, a, n_paths);
+        return;
+    }
+    static int grid = 0;
+    if (!grid) grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace));
+    const long long blocks_needed = (total + 255) / 256;
+    const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
+    (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
+    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, n_paths, queue, slow_list, slow_cap, persistent_chunk(total, g));
+    hipLaunchKernelGGL(k_wf_trace_slow, dim3(64), dim3(256), 0, st, S, a, n_paths, queue, slow_list, slow_cap);
 }
 
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)

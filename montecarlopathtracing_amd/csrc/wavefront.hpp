@@ -36,6 +36,12 @@ struct WfRays {             // written by logic(d), consumed by trace(d); slot (
     double* d;              // [nl+1][3][cap]
 };
 
+struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
+    unsigned long long head;        // next unclaimed ray slot
+    unsigned int slow_count;        // rays deferred to the reference-shaped walk (may exceed the list capacity)
+    unsigned int pad[13];
+};
+
 struct WfCounts {           // device-side counters of one iteration
     unsigned int n_next;    // paths alive after compaction
     unsigned int pad[15];
@@ -55,6 +61,7 @@ struct WfArgs {
     double* rad;                // [chunk samples][3] finished radiance
     WfCounts* counts;           // counts[0] = this iteration's output
     DCounters* ctr;
+    const DTri* tris;           // S.tris (material of a shadow ray's hit)
 };
 
 size_t wf_bytes_per_path(int nl);
@@ -62,7 +69,10 @@ size_t wf_bytes_per_path(int nl);
 bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& a, WfState& b, WfRays& r);
 
 void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_prev, bool first, hipStream_t st);
-void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, hipStream_t st);
+void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, TraceQueue* queue, long long* slow_list,
+                     unsigned int slow_cap, hipStream_t st);
+int persistent_grid(const void* kernel);
+long long persistent_chunk(long long total, int grid_blocks);
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st);
 void launch_zero_rad(double* rad, long long n_doubles, hipStream_t st);
 
