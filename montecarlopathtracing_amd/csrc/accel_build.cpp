@@ -15,6 +15,7 @@
 // fetch tests both children.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -25,8 +26,9 @@ namespace mcpt {
 namespace {
 
 constexpr int kBins = 16;
-constexpr double kCostNode = 1.0;   // relative cost of one inner step (two conservative box tests)
-constexpr double kCostTri = 1.6;    // relative cost of one leaf triangle (cheap box reject + some exact tests)
+double kCostNode = 1.0;   // relative cost of one inner step (two conservative box tests)
+double kCostTri = 1.6;    // relative cost of one leaf triangle (cheap box reject + some exact tests)
+int kMaxLeafRt = kFastMaxLeaf;
 
 struct Box {
     double lo[3], hi[3];
@@ -117,7 +119,7 @@ struct Builder {
             }
             if (best_axis >= 0) {
                 const double split_cost = kCostNode + kCostTri * best / std::max(parent_area, 1e-300);
-                if (n <= kFastMaxLeaf && kCostTri * n <= split_cost) return make_leaf(b, e);
+                if (n <= kMaxLeafRt && kCostTri * n <= split_cost) return make_leaf(b, e);
                 const int a = best_axis;
                 const double ext = cb.hi[a] - cb.lo[a];
                 const double scale = kBins * (1.0 - 1e-12) / ext;
@@ -130,7 +132,7 @@ struct Builder {
                 });
                 mid = int(it - idx.begin());
                 if (mid == b || mid == e) mid = -1;
-            } else if (n <= kFastMaxLeaf) {
+            } else if (n <= kMaxLeafRt) {
                 return make_leaf(b, e);     // all centroids coincide
             }
         }
@@ -162,6 +164,8 @@ struct Builder {
 void build_fast_bvh(const Scene& s, FastBvh& out)
 {
     out = FastBvh();
+    if (const char* e = std::getenv("MCPT_FAST_LEAF")) kMaxLeafRt = std::max(1, std::min(kFastMaxLeaf, std::atoi(e)));
+    if (const char* e = std::getenv("MCPT_FAST_CT")) kCostTri = std::atof(e);
     const int t = s.bi.t;
     std::vector<Box> prim(t);
     const int leaf0 = find_index(s.bi, (1 << s.bi.Level) - 1, s.bi.Level);

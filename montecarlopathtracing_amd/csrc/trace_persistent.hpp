@@ -84,12 +84,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                             sp = 0; cur = 0; state = ST_INNER;
                         } else {
                             const unsigned int at = atomicAdd(&queue->slow_count, 1u);
-                            if (at < slow_cap) slow_list[at] = q;
-                            else {                       // side list full: walk it here
-                                Hit h;
-                                const bool ok = trace_closest(S, nr, h, w);
-                                src.store(q, ok, h);
-                            }
+                            if (at < slow_cap) slow_list[at] = q;    // list full: the second pass scans every slot instead
                         }
                     }
                 }
@@ -169,20 +164,33 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     }
 }
 
-// second pass: the deferred rays, one lane each, reference-shaped walk
+// second pass: the deferred rays, one lane each, reference-shaped walk.  If more rays were deferred than the side list
+// holds (pathological input), every slot is scanned and the rays that failed fast_path_ok() are recognised again.
 template <class Src>
 __device__ __forceinline__ void trace_slow_list(const DScene& S, const Src& src, const TraceQueue* queue, const long long* __restrict__ slow_list,
                                                 unsigned int slow_cap, Work& w)
 {
-    unsigned int n = queue->slow_count;
-    if (n > slow_cap) n = slow_cap;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const long long q = slow_list[i];
-        Ray r;
-        if (!src.fetch(q, r)) continue;
-        Hit h;
-        const bool ok = trace_closest(S, r, h, w);
-        src.store(q, ok, h);
+    const unsigned int n = queue->slow_count;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n <= slow_cap) {
+        for (long long i = first; i < n; i += stride) {
+            const long long q = slow_list[i];
+            Ray r;
+            if (!src.fetch(q, r)) continue;
+            Hit h;
+            const bool ok = trace_closest(S, r, h, w);
+            src.store(q, ok, h);
+        }
+    } else {
+        const long long total = src.total();
+        for (long long q = first; q < total; q += stride) {
+            Ray r;
+            if (!src.fetch(q, r) || fast_path_ok(S.fast, r)) continue;
+            Hit h;
+            const bool ok = trace_closest(S, r, h, w);
+            src.store(q, ok, h);
+        }
     }
 }
 

@@ -392,7 +392,13 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool f
     const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
     hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, n_paths, queue, slow_list, slow_cap, persistent_chunk(total, g));
-    hipLaunchKernelGGL(k_wf_trace_slow, dim3(64), dim3(256), 0, st, S, a, n_paths, queue, slow_list, slow_cap);
+    hipLaunchKernelGGL(k_wf_trace_slow, dim3(256), dim3(256), 0, st, S, a, n_paths, queue, slow_list, slow_cap);
+}
+
+void launch_wf_trace_reference(const DScene& S, const WfArgs& a, long long n_paths, hipStream_t st)
+{
+    if (n_paths <= 0) return;
+    hipLaunchKernelGGL(k_wf_trace_reference, dim3(grid_for(n_paths * (a.nl + 1), 256, 1u << 30)), dim3(256), 0, st, S, a, n_paths);
 }
 
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)

@@ -71,6 +71,7 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& a, WfSta
 void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_prev, bool first, hipStream_t st);
 void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, TraceQueue* queue, long long* slow_list,
                      unsigned int slow_cap, hipStream_t st);
+void launch_wf_trace_reference(const DScene& S, const WfArgs& a, long long n_paths, hipStream_t st);
 int persistent_grid(const void* kernel);
 long long persistent_chunk(long long total, int grid_blocks);
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st);
