@@ -121,8 +121,8 @@ int  mcpt_device_set_trace_mode(mcpt_device*, int32_t mode);
 
 /* ---- closest hit (ray_intersect) ---- */
 /* rays: n x 6 doubles (origin xyz, direction xyz).  face[n] = .obj face index or -1, t[n], p[n*3], pn[n*3];
- * any output may be NULL.  Host-pointer form stages through HBM; the _device form takes device pointers and a
- * hipStream_t (NULL = default stream) and is asynchronous. */
+ * any output of the host-pointer form may be NULL.  It stages through HBM; the _device form takes device pointers
+ * (d_pn may be NULL, the others are required) and a hipStream_t (NULL = default stream) and is asynchronous. */
 int  mcpt_trace_closest(mcpt_device*, const double* rays, int64_t n, int32_t* face, double* t, double* p, double* pn, mcpt_stats* stats);
 int  mcpt_trace_closest_device(mcpt_device*, const double* d_rays, int64_t n, int32_t* d_face, double* d_t, double* d_p, double* d_pn, void* stream);
 

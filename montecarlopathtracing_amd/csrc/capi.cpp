@@ -376,6 +376,7 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
     HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->wf_counts), sizeof(WfCounts)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->queue), sizeof(TraceQueue)));
+    if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->slow_list), size_t(d->slow_cap) * sizeof(long long)));
     if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
         const double v = std::atof(gb);
@@ -434,7 +435,9 @@ int mcpt_trace_closest_device(mcpt_device* d, const double* d_rays, int64_t n, i
 {
     if (!d || (n > 0 && !d_rays) || n < 0) return fail(MCPT_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(d->ordinal));
-    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, static_cast<hipStream_t>(stream));
+    if (!d_face || !d_t || !d_p) return fail(MCPT_ERR_ARG, "d_face, d_t and d_p are required by the device form");
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->queue, d->slow_list, d->slow_cap,
+                         static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
     return MCPT_OK;
 }
@@ -457,7 +460,7 @@ int mcpt_trace_closest(mcpt_device* d, const double* rays, int64_t n, int32_t* f
     TRY_OR_CLEAN(hipMemcpyAsync(d_rays, rays, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice, d->stream));
     TRY_OR_CLEAN(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), d->stream));
     TRY_OR_CLEAN(hipEventRecord(d->ev[0], d->stream));
-    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->stream);
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->queue, d->slow_list, d->slow_cap, d->stream);
     TRY_OR_CLEAN(hipGetLastError());
     TRY_OR_CLEAN(hipEventRecord(d->ev[1], d->stream));
     if (face) TRY_OR_CLEAN(hipMemcpyAsync(face, d_face, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
@@ -636,7 +639,7 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
     if ((rc = grow(&d->hits, &d->hits_cap, npx))) return rc;
     HIP_TRY(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), st));
     HIP_TRY(hipEventRecord(d->ev[0], st));
-    launch_primary_hits(d->ds, d->trace_mode == MCPT_TRACE_FAST, d->dirs, d->pixels, int(npx), d->hits, d->ctr, st);
+    launch_primary_hits(d->ds, d->trace_mode == MCPT_TRACE_FAST, d->dirs, d->pixels, int(npx), d->hits, d->ctr, d->queue, d->slow_list, d->slow_cap, st);
     HIP_TRY(hipGetLastError());
     double ms_trace = 0;
     int launches = 0;
@@ -653,6 +656,7 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
         stats->ms_total = ms; stats->ms_trace = ms_trace; stats->launches = launches;
         stats->samples = uint64_t(npx) * uint64_t(p->spp);      // camera samples covered (a primary miss is a finished sample)
+        stats->rays_primary = uint64_t(npx);
     }
     return MCPT_OK;
 }

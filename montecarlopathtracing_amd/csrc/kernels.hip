@@ -9,7 +9,7 @@
 #include "dev_common.hpp"
 #include "kernels.hpp"
 #include "shade_common.hpp"
-#include "trace_fast.hpp"
+#include "trace_persistent.hpp"
 
 namespace mcpt {
 
@@ -42,6 +42,79 @@ __global__ void __launch_bounds__(256) k_trace_closest(DScene S, const double* _
         if (face) face[gid] = ok ? S.tris[h.leaf].face : -1;
         if (t_out) t_out[gid] = ok ? h.t : 0.0;
         if (p_out) { p_out[gid * 3] = h.p.x; p_out[gid * 3 + 1] = h.p.y; p_out[gid * 3 + 2] = h.p.z; }
+        if (pn_out) { pn_out[gid * 3] = pn.x; pn_out[gid * 3 + 1] = pn.y; pn_out[gid * 3 + 2] = pn.z; }
+    }
+    flush_stats(ctr, ls);
+}
+
+// ---- persistent fast walk over a plain ray array (mcpt_trace_closest) and over the primary rays
+struct ArrayRaySource {
+    const double* rays; long long n;
+    int32_t* leaf_out; double* t_out; double* p_out;     // leaf_out receives the LEAF index; k_finish_hits turns it into a face
+    __device__ __forceinline__ long long total() const { return n; }
+    __device__ __forceinline__ bool fetch(long long q, Ray& r) const { r.o = ld3(rays + q * 6); r.d = ld3(rays + q * 6 + 3); return true; }
+    __device__ __forceinline__ void store(long long q, bool ok, const Hit& h) const
+    {
+        leaf_out[q] = ok ? h.leaf : -1;
+        t_out[q] = ok ? h.t : 0.0;
+        p_out[q * 3] = h.p.x; p_out[q * 3 + 1] = h.p.y; p_out[q * 3 + 2] = h.p.z;
+    }
+};
+
+struct PrimaryRaySource {
+    const double* dirs; const int32_t* pixels; int n_pixels; double eye[3]; PrimaryHit* hits;
+    __device__ __forceinline__ long long total() const { return n_pixels; }
+    __device__ __forceinline__ bool fetch(long long q, Ray& r) const
+    {
+        const int pix = pixels ? pixels[q] : (int)q;
+        r.o = ld3(eye); r.d = ld3(dirs + (size_t)pix * 3);
+        return true;
+    }
+    __device__ __forceinline__ void store(long long q, bool ok, const Hit& h) const
+    {
+        PrimaryHit ph;
+        ph.leaf = ok ? h.leaf : -1; ph.pad = 0; ph.t = h.t; ph.p[0] = h.p.x; ph.p[1] = h.p.y; ph.p[2] = h.p.z;
+        hits[q] = ph;
+    }
+};
+
+template <class Src>
+__global__ void __launch_bounds__(256) k_trace_persistent(DScene S, Src src, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
+                                                          long long chunk, DCounters* ctr)
+{
+    __shared__ int lds_stack[MCPT_FAST_STACK * 256];
+    LaneStats ls;
+    Work w = {0, 0};
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, w);
+    ls.nodes = w.nodes; ls.tris = w.tris;
+    flush_stats(ctr, ls);
+}
+
+template <class Src>
+__global__ void __launch_bounds__(256) k_trace_slow(DScene S, Src src, const TraceQueue* queue, const long long* slow_list, unsigned int slow_cap,
+                                                    DCounters* ctr)
+{
+    LaneStats ls;
+    Work w = {0, 0};
+    trace_slow_list(S, src, queue, slow_list, slow_cap, w);
+    ls.nodes = w.nodes; ls.tris = w.tris;
+    flush_stats(ctr, ls);
+}
+
+// leaf index -> .obj face index, interpolated normal of the accepted hit
+__global__ void k_finish_hits(DScene S, long long n, int32_t* __restrict__ face, const double* __restrict__ p, double* __restrict__ pn_out, DCounters* ctr)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    LaneStats ls;
+    if (gid < n) {
+        ls.primary = 1;
+        const int leaf = face[gid];
+        V3 pn = mk(0, 0, 0);
+        if (leaf >= 0) {
+            Hit h; h.leaf = leaf; h.t = 0; h.p = ld3(p + gid * 3);
+            pn = hit_normal(S, h);
+            face[gid] = S.tris[leaf].face;
+        }
         if (pn_out) { pn_out[gid * 3] = pn.x; pn_out[gid * 3 + 1] = pn.y; pn_out[gid * 3 + 2] = pn.z; }
     }
     flush_stats(ctr, ls);
@@ -287,23 +360,47 @@ __global__ void k_fold_samples(const double* __restrict__ rad, const int32_t* __
 // ------------------------------------------------------------------------------------------------ launchers
 static inline unsigned blocks_for(long long n, int block) { return (unsigned)((n + block - 1) / block); }
 
+template <class Src>
+static void launch_persistent(const DScene& S, const Src& src, long long total, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
+                              DCounters* ctr, hipStream_t st)
+{
+    static int grid = 0;
+    if (!grid) grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<Src>));
+    const long long blocks_needed = (total + 255) / 256;
+    const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
+    (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
+    hipLaunchKernelGGL(k_trace_persistent<Src>, dim3(g), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, persistent_chunk(total, g), ctr);
+    hipLaunchKernelGGL(k_trace_slow<Src>, dim3(256), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, ctr);
+}
+
+// d_face, d_t, d_p must be non-null device buffers (the C-ABI layer always allocates them); d_pn may be null
 void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long long n, int32_t* d_face, double* d_t, double* d_p,
-                          double* d_pn, DCounters* ctr, hipStream_t st)
+                          double* d_pn, DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st)
 {
     if (n <= 0) return;
-    if (fast) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, d_rays, n, d_face, d_t, d_p, d_pn, ctr);
-    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, d_rays, n, d_face, d_t, d_p, d_pn, ctr);
+    if (!fast) {
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, d_rays, n, d_face, d_t, d_p, d_pn, ctr);
+        return;
+    }
+    ArrayRaySource src; src.rays = d_rays; src.n = n; src.leaf_out = d_face; src.t_out = d_t; src.p_out = d_p;
+    launch_persistent(S, src, n, queue, slow_list, slow_cap, ctr, st);
+    hipLaunchKernelGGL(k_finish_hits, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, n, d_face, d_p, d_pn, ctr);
 }
 void launch_primary_dirs(const DCamera& cam, double* d_dirs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_primary_dirs, dim3(blocks_for(cam.height, 64)), dim3(64), 0, st, cam, d_dirs);
 }
 void launch_primary_hits(const DScene& S, bool fast, const double* d_dirs, const int32_t* d_pixels, int n_pixels, PrimaryHit* d_hits,
-                         DCounters* ctr, hipStream_t st)
+                         DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st)
 {
     if (n_pixels <= 0) return;
-    if (fast) hipLaunchKernelGGL(k_primary_hits<true>, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, st, S, d_dirs, d_pixels, n_pixels, d_hits, ctr);
-    else hipLaunchKernelGGL(k_primary_hits<false>, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, st, S, d_dirs, d_pixels, n_pixels, d_hits, ctr);
+    if (!fast) {
+        hipLaunchKernelGGL(k_primary_hits<false>, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, st, S, d_dirs, d_pixels, n_pixels, d_hits, ctr);
+        return;
+    }
+    PrimaryRaySource src; src.dirs = d_dirs; src.pixels = d_pixels; src.n_pixels = n_pixels; src.hits = d_hits;
+    src.eye[0] = S.cam.eye[0]; src.eye[1] = S.cam.eye[1]; src.eye[2] = S.cam.eye[2];
+    launch_persistent(S, src, n_pixels, queue, slow_list, slow_cap, ctr, st);
 }
 void launch_shade_samples(const DScene& S, unsigned long long seed, const double* d_dirs, const int32_t* d_pixels,
                           const PrimaryHit* d_hits, int first_slot, int n_slots, int spp, double* d_rad, DCounters* ctr, hipStream_t st)

@@ -83,6 +83,25 @@ def test_fast_walk_equals_reference_walk_bulk(pair, mcpt):
     assert np.array_equal(_bits(rpn[h]), _bits(fpn[h]))
 
 
+def test_deferred_ray_list_overflow(oracle, mcpt, monkeypatch):
+    """Rays with a zero direction component are deferred to the reference-shaped walk through a side list; with the list
+    shrunk to 8 entries the second pass must recognise them by scanning.  Results stay bit-exact."""
+    monkeypatch.setenv("MCPT_SLOW_LIST", "8")
+    osc = oracle.OracleScene(SCENES + "veach-mis", texture_dir=SCENES, width=64, height=48)
+    sc = mcpt.Scene(SCENES, "veach-mis", width=64, height=48)
+    dev = mcpt.Device(sc, 0)
+    rays = make_rays(osc, 20000, seed=77)
+    assert int((rays[:, 3:] == 0).any(axis=1).sum()) > 100
+    of, ot, op, opn = osc.trace_closest(rays)
+    gf, gt, gp, gpn = dev.ray_intersect(rays)
+    assert np.array_equal(of, gf)
+    h = of >= 0
+    assert np.array_equal(_bits(ot[h]), _bits(gt[h])) and np.array_equal(_bits(opn[h]), _bits(gpn[h]))
+    dev.close()
+    sc.close()
+    osc.close()
+
+
 def test_sample_radiance(pair, oracle, mcpt):
     name, osc, sc, dev = pair
     rng = np.random.default_rng(5)
