@@ -1,0 +1,52 @@
+"""Not gpu: the N>1 path of bench.py / dist.py with world_size 2 on the gloo backend.  The tiles come from the CPU oracle
+(test infrastructure) so that the partition + gather + scatter assembly is checked end to end without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, SCENES
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import montecarlopathtracing_amd as M
+    from montecarlopathtracing_amd.dist import gather_frame, scatter_into_frame
+    import oracle_lib as O
+    W, H = 96, 40
+    sc = M.Scene(SCENES, "veach-mis", width=W, height=H)
+    lists = [sc.owned_pixels(r, world) for r in range(world)]
+    counts = [len(l) for l in lists]
+    # every rank renders ONLY its own pixels (oracle, deterministic in (pixel, sample) -> independent of the rank count)
+    osc = O.OracleScene(SCENES + "veach-mis", texture_dir=SCENES, width=W, height=H)
+    full = osc.render(2, seed=11)
+    local = torch.zeros((H * W, 3), dtype=torch.float64)
+    mine = torch.from_numpy(lists[rank].astype(np.int64))
+    local[mine] = torch.from_numpy(full.reshape(-1, 3))[mine]
+    bufs = gather_frame(local, mine, counts, rank, world)
+    if rank == 0:
+        frame = torch.zeros((H * W, 3), dtype=torch.float64)
+        scatter_into_frame(frame, bufs, [torch.from_numpy(l.astype(np.int64)) for l in lists])
+        np.save(os.path.join(tmp, "frame.npy"), frame.numpy().reshape(H, W, 3))
+        np.save(os.path.join(tmp, "full.npy"), full)
+    else:
+        assert bufs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gather_assembles_the_frame(world, tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    frame = np.load(tmp_path / "frame.npy")
+    full = np.load(tmp_path / "full.npy")
+    assert np.array_equal(frame.view(np.uint64), full.view(np.uint64))

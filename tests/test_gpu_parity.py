@@ -10,6 +10,10 @@ from conftest import SCENES, make_rays
 
 pytestmark = pytest.mark.gpu
 
+import os  # noqa: E402
+
+from conftest import ROOT  # noqa: E402
+
 REL_TOL = 1e-9
 
 
@@ -152,3 +156,34 @@ def test_partition_independent(pair, mcpt):
     for r in range(3):
         dev.generateImg(4, seed=9, rank=r, world=3, img=parts)
     assert np.array_equal(_bits(full), _bits(parts))
+
+
+def _blocks(img8, b):
+    h, w, _ = img8.shape
+    hh, ww = (h // b) * b, (w // b) * b
+    return img8[:hh, :ww].astype(np.float32).reshape(hh // b, b, ww // b, b, 3).mean(axis=(1, 3))
+
+
+def test_published_renders_full_resolution(mcpt):
+    """The reference's own published renders (time-seeded, so statistical): full native resolution and the published SPP
+    on the GPU, 16x16-block means against tests/golden/published_renders.npz."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "published_renders.npz"))
+    sc = mcpt.Scene(SCENES, "cornell-box")                  # native 1024x1024 camera
+    dev = mcpt.Device(sc, 0)
+    mine = _blocks(mcpt.imshow_rgb8(dev.generateImg(25, seed=1)), 16)
+    pub = g["cornell_spp25"]
+    assert abs(mine.mean() - pub.mean()) < 0.01 * pub.mean(), (mine.mean(), pub.mean())
+    assert np.corrcoef(mine.ravel(), pub.ravel())[0, 1] > 0.99
+    assert np.sqrt(((mine - pub) ** 2).mean()) < 6.0
+    dev.close()
+    sc.close()
+    sc = mcpt.Scene(SCENES, "veach-mis")                    # native 1200x900
+    dev = mcpt.Device(sc, 0)
+    img = mcpt.imshow_rgb8(dev.generateImg(100, seed=1))
+    mine = _blocks(img[:896], 16)
+    pub = g["veach_spp100"]
+    assert mine.shape == pub.shape
+    assert abs(mine.mean() - pub.mean()) < 0.01 * pub.mean(), (mine.mean(), pub.mean())
+    assert np.corrcoef(mine.ravel(), pub.ravel())[0, 1] > 0.99
+    dev.close()
+    sc.close()
