@@ -28,7 +28,7 @@ namespace {
 constexpr int kBins = 16;
 double kCostNode = 1.0;   // relative cost of one inner step (two conservative box tests)
 double kCostTri = 1.6;    // relative cost of one leaf triangle (cheap box reject + some exact tests)
-int kMaxLeafRt = kFastMaxLeaf;
+int kMaxLeafRt = kFastDefaultLeaf;
 
 struct Box {
     double lo[3], hi[3];
@@ -161,6 +161,110 @@ struct Builder {
 
 }  // namespace
 
+namespace {
+
+// ---- collapse the binary tree into compressed 4-wide nodes -----------------------------------------------------------
+struct Collapser {
+    const FastBvh& in;
+    std::vector<CwNode>& out;
+    std::vector<int> height;            // binary height below each FastNode
+
+    int compute_height(int n)
+    {
+        int h = 0;
+        for (int c = 0; c < 2; c++) {
+            const int32_t r = in.nodes[n].child[c];
+            if (r >= 0) h = std::max(h, 1 + compute_height(r));
+            else h = std::max(h, 1);
+        }
+        return height[n] = h;
+    }
+
+    struct Kid { int32_t ref; double lo[3], hi[3]; };
+
+    static double area(const Kid& k)
+    {
+        const double dx = k.hi[0] - k.lo[0], dy = k.hi[1] - k.lo[1], dz = k.hi[2] - k.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    // budget = stack entries still available on the path to this node; guarantees need(node) <= budget
+    int32_t emit(int n, int budget, int& need)
+    {
+        std::vector<Kid> kids;
+        auto kid_of = [&](int parent, int c) {
+            Kid k; k.ref = in.nodes[parent].child[c];
+            for (int a = 0; a < 3; a++) { k.lo[a] = in.nodes[parent].lo[c][a]; k.hi[a] = in.nodes[parent].hi[c][a]; }
+            return k;
+        };
+        for (int c = 0; c < 2; c++) if (in.nodes[n].child[c] != kFastEmpty) kids.push_back(kid_of(n, c));
+        // widen: open the inner child with the largest area while the stack budget allows one more sibling
+        while (kids.size() < 4) {
+            int pick = -1; double best = -1;
+            for (size_t i = 0; i < kids.size(); i++)
+                if (kids[i].ref >= 0 && area(kids[i]) > best) { best = area(kids[i]); pick = int(i); }
+            if (pick < 0) break;
+            // after opening there are kids.size()+1 children -> kids.size() pushes at this node; every inner child must
+            // still fit: height(child) <= budget - pushes
+            const int pushes = int(kids.size());
+            bool fits = true;
+            for (size_t i = 0; i < kids.size(); i++) {
+                if (int(i) == pick) {
+                    for (int c = 0; c < 2; c++) { const int32_t r = in.nodes[kids[i].ref].child[c]; if (r >= 0 && height[r] > budget - pushes) fits = false; }
+                } else if (kids[i].ref >= 0 && height[kids[i].ref] > budget - pushes) fits = false;
+            }
+            if (!fits) break;
+            const int open = kids[pick].ref;
+            kids.erase(kids.begin() + pick);
+            for (int c = 0; c < 2; c++) if (in.nodes[open].child[c] != kFastEmpty) kids.push_back(kid_of(open, c));
+        }
+        const int32_t self = int32_t(out.size());
+        out.emplace_back();
+        const int pushes = int(kids.size()) - 1;
+        int below = 0;
+        int32_t refs[4] = {kFastEmpty, kFastEmpty, kFastEmpty, kFastEmpty};
+        for (size_t i = 0; i < kids.size(); i++) {
+            if (kids[i].ref >= 0) { int nd = 0; refs[i] = emit(kids[i].ref, budget - pushes, nd); below = std::max(below, nd); }
+            else refs[i] = kids[i].ref;
+        }
+        need = pushes + below;
+        // quantise
+        CwNode nd{};
+        nd.nchild = uint8_t(kids.size());
+        for (int a = 0; a < 3; a++) {
+            double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+            for (const Kid& k : kids) { lo = std::min(lo, k.lo[a]); hi = std::max(hi, k.hi[a]); }
+            float pf = float(lo);
+            if (double(pf) > lo) pf = std::nextafter(pf, -std::numeric_limits<float>::infinity());
+            const double p = double(pf);
+            int e = -126;
+            const double ext = hi - p;
+            if (ext > 0) e = std::max(-126, int(std::ceil(std::log2(ext / 255.0))));
+            for (;;) {
+                const double sc = std::ldexp(1.0, e);
+                bool ok = p + 255.0 * sc >= hi;
+                uint32_t wlo = 0, whi = 0;
+                for (size_t i = 0; ok && i < kids.size(); i++) {
+                    double ql = std::floor((kids[i].lo[a] - p) / sc), qh = std::ceil((kids[i].hi[a] - p) / sc);
+                    ql = std::min(std::max(ql, 0.0), 255.0); qh = std::min(std::max(qh, 0.0), 255.0);
+                    while (ql > 0 && p + ql * sc > kids[i].lo[a]) ql -= 1;
+                    while (qh < 255 && p + qh * sc < kids[i].hi[a]) qh += 1;
+                    if (p + ql * sc > kids[i].lo[a] || p + qh * sc < kids[i].hi[a]) ok = false;
+                    wlo |= uint32_t(ql) << (8 * i); whi |= uint32_t(qh) << (8 * i);
+                }
+                if (ok) { nd.qlo[a] = wlo; nd.qhi[a] = whi; break; }
+                e++;
+            }
+            nd.p[a] = pf; nd.e[a] = int8_t(e);
+        }
+        for (int i = 0; i < 4; i++) nd.child[i] = refs[i];
+        out[self] = nd;
+        return self;
+    }
+};
+
+}  // namespace
+
 void build_fast_bvh(const Scene& s, FastBvh& out)
 {
     out = FastBvh();
@@ -195,6 +299,12 @@ void build_fast_bvh(const Scene& s, FastBvh& out)
         nd.child[0] = root; nd.child[1] = kFastEmpty;
         out.nodes.push_back(nd);
     }
+    Collapser col{out, out.cw, std::vector<int>(out.nodes.size(), 0)};
+    col.compute_height(0);
+    out.cw.reserve(out.nodes.size());
+    int need = 0;
+    col.emit(0, kFastMaxDepth - 1, need);
+    out.cw_stack_need = need;
 }
 
 }  // namespace mcpt

@@ -9,10 +9,13 @@
 namespace mcpt {
 
 constexpr int kFastMaxDepth = 32;          // inner levels; bounds the per-lane LDS stack
-constexpr int kFastMaxLeaf = 4;            // triangles per leaf
+constexpr int kFastMaxLeaf = 4;            // most triangles a leaf may hold (3 bits of the reference; bit 3 is a runtime flag)
+constexpr int kFastDefaultLeaf = 4;        // default leaf size (measured: 4 beats 1 and 2 on MI355X; inner steps cost more than leaf boxes)
 constexpr int32_t kFastEmpty = INT32_MIN;  // child reference of an absent child
 
 struct FastBvh {
+    std::vector<CwNode> cw;                // compressed 4-wide collapse of `nodes` (what the kernels walk)
+    int cw_stack_need = 0;                 // worst-case traversal stack entries
     std::vector<FastNode> nodes;
     std::vector<int32_t> leaf_tris;        // reference leaf index k of every slot of the leaf triangle list
     double scene_absmax = 0;               // largest |coordinate| of any leaf box

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <array>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -63,7 +65,7 @@ struct mcpt_device {
     // scene arrays
     DNode* nodes = nullptr; DTri* tris = nullptr; DTriShade* shade = nullptr; DMaterial* materials = nullptr;
     DLight* lights = nullptr; DLightTri* light_tris = nullptr; double* light_cdf = nullptr; uint8_t* texels = nullptr;
-    FastNode* fast_nodes = nullptr; DTri* fast_tris = nullptr;
+    FastNode* fast_nodes = nullptr; DTri* fast_tris = nullptr; CwNode* cw_nodes = nullptr;
     int trace_mode = MCPT_TRACE_FAST;
     // frame state
     int width = 0, height = 0;
@@ -221,7 +223,7 @@ int mcpt_scene_fast_bvh_stats(const mcpt_scene* h, int32_t* n_nodes, int32_t* ma
                 };
                 if (ref >= 0) { inside(fb.nodes[ref].lo[0], fb.nodes[ref].hi[0]); if (fb.nodes[ref].child[1] != kFastEmpty) inside(fb.nodes[ref].lo[1], fb.nodes[ref].hi[1]); }
                 else {
-                    const int r = -1 - ref, first = r >> 4, count = (r & 15) + 1;
+                    const int r = -1 - ref, first = r >> 4, count = (r & 7) + 1;
                     for (int i = 0; i < count; i++) {
                         const NodeBox& b = s.nodes[leaf0 + fb.leaf_tris[first + i]];
                         const double lo[3] = {b.min_x, b.min_y, b.min_z}, hi[3] = {b.max_x, b.max_y, b.max_z};
@@ -229,6 +231,50 @@ int mcpt_scene_fast_bvh_stats(const mcpt_scene* h, int32_t* n_nodes, int32_t* ma
                     }
                 }
             }
+        // compressed nodes: every decoded child box must contain the fp64 box of what it refers to
+        {
+            std::vector<std::array<double, 6>> cwbox(fb.cw.size());     // fp64 box of each CwNode (union of its children's true boxes)
+            std::vector<int> bin_of(fb.cw.size(), -1);
+            // recompute true boxes bottom-up through the binary tree: box of a FastNode child is stored in its parent
+            std::function<void(int, int, const double*, const double*)> walk;   // (cw node, unused, lo, hi)
+            auto leaf_box = [&](int32_t ref, double lo[3], double hi[3]) {
+                const int r = -1 - ref, first = r >> 4, count = (r & 7) + 1;
+                for (int a = 0; a < 3; a++) { lo[a] = 1e300; hi[a] = -1e300; }
+                for (int i = 0; i < count; i++) {
+                    const NodeBox& b = s.nodes[leaf0 + fb.leaf_tris[first + i]];
+                    const double l[3] = {b.min_x, b.min_y, b.min_z}, h2[3] = {b.max_x, b.max_y, b.max_z};
+                    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h2[a]); }
+                }
+            };
+            std::function<void(int, double*, double*)> true_box = [&](int n, double* lo, double* hi) {
+                for (int a = 0; a < 3; a++) { lo[a] = 1e300; hi[a] = -1e300; }
+                const CwNode& nd = fb.cw[n];
+                for (int c = 0; c < 4; c++) {
+                    if (nd.child[c] == kFastEmpty) continue;
+                    double cl[3], ch[3];
+                    if (nd.child[c] >= 0) true_box(nd.child[c], cl, ch); else leaf_box(nd.child[c], cl, ch);
+                    for (int a = 0; a < 3; a++) {
+                        const double sc = std::ldexp(1.0, nd.e[a]);
+                        const double dl = double(nd.p[a]) + double((nd.qlo[a] >> (8 * c)) & 255u) * sc;
+                        const double dh = double(nd.p[a]) + double((nd.qhi[a] >> (8 * c)) & 255u) * sc;
+                        if (dl > cl[a] || dh < ch[a]) ok = false;
+                        lo[a] = std::min(lo[a], cl[a]); hi[a] = std::max(hi[a], ch[a]);
+                    }
+                }
+            };
+            double lo[3], hi[3];
+            if (!fb.cw.empty()) true_box(0, lo, hi);
+            // every triangle slot must be reachable exactly once
+            std::vector<int> seen(fb.leaf_tris.size(), 0);
+            for (const CwNode& nd : fb.cw)
+                for (int c = 0; c < 4; c++)
+                    if (nd.child[c] < 0 && nd.child[c] != kFastEmpty) {
+                        const int r = -1 - nd.child[c], first = r >> 4, count = (r & 7) + 1;
+                        for (int i = 0; i < count; i++) seen[first + i]++;
+                    }
+            for (int v : seen) if (v != 1) ok = false;
+            if (fb.cw_stack_need >= kFastMaxDepth) ok = false;
+        }
         *nesting_ok = ok ? 1 : 0;
     }
     return MCPT_OK;
@@ -273,7 +319,7 @@ void mcpt_device_free(mcpt_device* d)
 {
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
-    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris,
+    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes,
                     d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->wf_counts, d->queue, d->slow_list};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -371,7 +417,7 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
                 const double a = std::fabs(v);
                 if (!(a == 0.0 || (a >= 1e-150 && a <= 1e150))) coords_ok = false;
             }
-    if ((rc = upload(fb.nodes, &d->fast_nodes)) || (rc = upload(ftris, &d->fast_tris))) return rc;
+    if ((rc = upload(fb.nodes, &d->fast_nodes)) || (rc = upload(ftris, &d->fast_tris)) || (rc = upload(fb.cw, &d->cw_nodes))) return rc;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->ctr), sizeof(DCounters)));
     HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->wf_counts), sizeof(WfCounts)));
@@ -389,8 +435,9 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
     S.t = t; S.Lv = s.bi.Lv; S.Level = s.bi.Level; S.Nr = s.bi.Nr;
     S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
     S.area0 = s.area0;
-    S.fast.nodes = d->fast_nodes; S.fast.tris = d->fast_tris; S.fast.absmax = fb.scene_absmax;
-    S.fast.enabled = (coords_ok && fb.max_depth < kFastMaxDepth) ? 1 : 0;
+    S.fast.cw = d->cw_nodes; S.fast.nodes = d->fast_nodes; S.fast.tris = d->fast_tris; S.fast.absmax = fb.scene_absmax;
+    S.fast.enabled = (coords_ok && fb.max_depth < kFastMaxDepth && fb.cw_stack_need < kFastMaxDepth && fb.scene_absmax >= 1e-15 &&
+                      fb.scene_absmax <= 1e15) ? 1 : 0;
     const CameraFrame cf = camera_frame(s);
     S.cam.eye[0] = cf.eye.x; S.cam.eye[1] = cf.eye.y; S.cam.eye[2] = cf.eye.z;
     S.cam.start_point[0] = cf.start_point.x; S.cam.start_point[1] = cf.start_point.y; S.cam.start_point[2] = cf.start_point.z;
@@ -426,7 +473,14 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
     s->rays_primary = c.rays_primary; s->rays_shadow = c.rays_shadow; s->rays_bounce = c.rays_bounce;
     s->node_visits = c.node_visits; s->tri_tests = c.tri_tests; s->shade_calls = c.shade_calls; s->samples = c.samples;
     s->shadow_skipped = c.shadow_skipped;
-    s->max_depth = int32_t(c.max_depth);
+    if (std::getenv("MCPT_PRINT_DIAG")) {
+        const double tot = double(c.pad[5] + c.pad[6] + c.pad[7]);
+        std::fprintf(stderr, "trace diag: inner iters %llu lanes %.1f/64 | tri iters %llu lanes %.1f/64 | idle lanes/iter %.1f | wave time: refill %.1f%% inner %.1f%% tri %.1f%% | cycles/inner iter %.0f cycles/tri iter %.0f\n",
+                     c.pad[0], c.pad[0] ? double(c.pad[1]) / c.pad[0] : 0.0, c.pad[2], c.pad[2] ? double(c.pad[3]) / c.pad[2] : 0.0,
+                     (c.pad[0] + c.pad[2]) ? double(c.pad[4]) / (c.pad[0] + c.pad[2]) : 0.0,
+                     tot ? 100.0 * c.pad[5] / tot : 0.0, tot ? 100.0 * c.pad[6] / tot : 0.0, tot ? 100.0 * c.pad[7] / tot : 0.0,
+                     c.pad[0] ? double(c.pad[6]) / c.pad[0] : 0.0, c.pad[2] ? double(c.pad[7]) / c.pad[2] : 0.0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ closest hit

@@ -123,7 +123,12 @@ __device__ __forceinline__ V3 barycentric(V3 v1, V3 v2, V3 v3, V3 p)
 }
 
 struct Hit { int leaf; double t; V3 p; };
-struct Work { uint32_t nodes, tris; };
+struct Work {
+    uint32_t nodes, tris;
+#ifdef MCPT_TRACE_DIAG
+    unsigned long long diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // inner iters, inner lanes, tri iters, tri lanes, idle lanes, cycles refill/inner/tri
+#endif
+};
 
 // ray_intersect / bvh_intersect (pathTracing.cpp:334-390) without recursion and without a stack.
 // The tree is the reference's implicit complete tree: node i (heap numbering) at level l has children 2i+1,

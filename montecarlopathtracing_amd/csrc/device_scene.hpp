@@ -41,7 +41,23 @@ struct alignas(128) FastNode {
     int32_t pad[6];
 };
 
+// Compressed 4-wide node, 64 B = one memory segment = four 16-B loads per lane per step (the walk is bound by L1 line
+// throughput, not by ALU or HBM): child boxes quantised to 8 bits per plane on a per-node grid
+//     plane = p[axis] + q * 2^e[axis],   q in 0..255, rounded outward at build time,
+// so the decoded box contains the child's fp64 box.  Only used to CULL; candidates are decided by the reference's
+// own fp64 tests.  child >= 0: node index; child < 0: leaf, -1-child = (first << 4) | (count-1); MCPT_FAST_EMPTY: none.
+struct alignas(64) CwNode {
+    float p[3];
+    int8_t e[3];
+    uint8_t nchild;
+    uint32_t qlo[3];           // [axis]: byte c = child c
+    uint32_t qhi[3];
+    int32_t child[4];
+    uint32_t pad[2];
+};
+
 struct DFast {
+    const CwNode* cw;          // compressed wide hierarchy (root = 0)
     const FastNode* nodes;
     const DTri* tris;          // DTri records permuted into fast-leaf order (leaf field = reference leaf index)
     double absmax;             // largest |coordinate| in the scene
@@ -93,7 +109,7 @@ struct DScene {
 struct DCounters {
     unsigned long long rays_primary, rays_shadow, rays_bounce, node_visits, tri_tests, shade_calls, samples, max_depth;
     unsigned long long shadow_skipped;   // shadow rays the reference traces although their result is never used (light behind the surface)
-    unsigned long long pad[7];
+    unsigned long long pad[15];   // diagnostics (MCPT_TRACE_DIAG builds)
 };
 
 }  // namespace mcpt

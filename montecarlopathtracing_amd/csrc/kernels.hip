@@ -14,28 +14,18 @@
 namespace mcpt {
 
 // ------------------------------------------------------------------------------------------------ kernels
-// closest hit of one ray with the selected walk; FAST needs this lane's LDS stack
-template <bool FAST>
-__device__ __forceinline__ bool trace_any(const DScene& S, const Ray& r, Hit& h, Work& w, int* lds_stack)
-{
-    if constexpr (FAST) return trace_closest_fast(S, r, h, w, lds_stack, 256);
-    else return trace_closest(S, r, h, w);
-}
-
-// mcpt_trace_closest: one lane per ray.
-template <bool FAST>
-__global__ void __launch_bounds__(256) k_trace_closest(DScene S, const double* __restrict__ rays, long long n,
+// mcpt_trace_closest with the reference-shaped walk: one lane per ray.
+__global__ void __launch_bounds__(256) k_trace_closest_reference(DScene S, const double* __restrict__ rays, long long n,
                                                        int32_t* __restrict__ face, double* __restrict__ t_out,
                                                        double* __restrict__ p_out, double* __restrict__ pn_out, DCounters* ctr)
 {
-    __shared__ int lds_stack[FAST ? MCPT_FAST_STACK * 256 : 1];
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     LaneStats ls;
     if (gid < n) {
         Ray r;
         r.o = ld3(rays + gid * 6); r.d = ld3(rays + gid * 6 + 3);
         Hit h; Work w = {0, 0};
-        const bool ok = trace_any<FAST>(S, r, h, w, lds_stack + threadIdx.x);
+        const bool ok = trace_closest(S, r, h, w);
         ls.nodes = w.nodes; ls.tris = w.tris; ls.primary = 1;
         V3 pn = mk(0, 0, 0);
         if (ok) pn = hit_normal(S, h);
@@ -83,9 +73,10 @@ __global__ void __launch_bounds__(256) k_trace_persistent(DScene S, Src src, Tra
                                                           long long chunk, DCounters* ctr)
 {
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
+    __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
     LaneStats ls;
     Work w = {0, 0};
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, w);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w);
     ls.nodes = w.nodes; ls.tris = w.tris;
     flush_stats(ctr, ls);
 }
@@ -138,11 +129,9 @@ __global__ void k_primary_dirs(DCamera cam, double* __restrict__ dirs)
 
 // One lane per owned pixel: the primary ray is the same for every sample of a pixel (no jitter,
 // pathTracing.cpp:306-308), so it is traced once.
-template <bool FAST>
-__global__ void __launch_bounds__(256) k_primary_hits(DScene S, const double* __restrict__ dirs, const int32_t* __restrict__ pixels,
+__global__ void __launch_bounds__(256) k_primary_hits_reference(DScene S, const double* __restrict__ dirs, const int32_t* __restrict__ pixels,
                                                       int n_pixels, PrimaryHit* __restrict__ hits, DCounters* ctr)
 {
-    __shared__ int lds_stack[FAST ? MCPT_FAST_STACK * 256 : 1];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     LaneStats ls;
     if (gid < n_pixels) {
@@ -150,7 +139,7 @@ __global__ void __launch_bounds__(256) k_primary_hits(DScene S, const double* __
         Ray r;
         r.o = ld3(S.cam.eye); r.d = ld3(dirs + (size_t)pix * 3);
         Hit h; Work w = {0, 0};
-        const bool ok = trace_any<FAST>(S, r, h, w, lds_stack + threadIdx.x);
+        const bool ok = trace_closest(S, r, h, w);
         ls.nodes = w.nodes; ls.tris = w.tris; ls.primary = 1;
         PrimaryHit ph;
         ph.leaf = ok ? h.leaf : -1; ph.pad = 0; ph.t = h.t; ph.p[0] = h.p.x; ph.p[1] = h.p.y; ph.p[2] = h.p.z;
@@ -379,7 +368,7 @@ void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long
 {
     if (n <= 0) return;
     if (!fast) {
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, d_rays, n, d_face, d_t, d_p, d_pn, ctr);
+        hipLaunchKernelGGL(k_trace_closest_reference, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, d_rays, n, d_face, d_t, d_p, d_pn, ctr);
         return;
     }
     ArrayRaySource src; src.rays = d_rays; src.n = n; src.leaf_out = d_face; src.t_out = d_t; src.p_out = d_p;
@@ -395,7 +384,7 @@ void launch_primary_hits(const DScene& S, bool fast, const double* d_dirs, const
 {
     if (n_pixels <= 0) return;
     if (!fast) {
-        hipLaunchKernelGGL(k_primary_hits<false>, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, st, S, d_dirs, d_pixels, n_pixels, d_hits, ctr);
+        hipLaunchKernelGGL(k_primary_hits_reference, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, st, S, d_dirs, d_pixels, n_pixels, d_hits, ctr);
         return;
     }
     PrimaryRaySource src; src.dirs = d_dirs; src.pixels = d_pixels; src.n_pixels = n_pixels; src.hits = d_hits;

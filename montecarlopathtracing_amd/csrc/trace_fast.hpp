@@ -5,15 +5,15 @@
 // whose coordinates obey the same bound, ray_intersect's answer is the lexicographic minimum of (t_k, k) over the
 // leaves k whose OWN box passes the reference's slab test, whose triangle test passes and whose t_k > 0.
 // This walk
-//   * culls inner nodes with a conservative slab test: the same (b-o) numerators, multiplied by 1/d instead of
-//     divided, differ from the reference's quotients by < 3 ulp, so comparing with a 2^-48 relative slack never
-//     rejects a box the reference would accept, and by monotonicity never loses a leaf below it;
+//   * culls inner nodes conservatively on a compressed 4-wide hierarchy (CwNode: 8-bit child boxes rounded outward,
+//     tested in fp32 with a rigorous error pad, see make_rayf): a box the reference would accept is never rejected,
+//     and by monotonicity no leaf below it is lost;
 //   * prunes by distance only beyond best_t + margin, margin = 1e-9 * scale / min|d_k| (>= 1e6 times the rounding
 //     error of t_k = (p.x-o.x)/d.x relative to the slab entry), and not at all when min|d_k| < 1e-6;
 //   * decides a triangle's own box from the same cheap interval when the outcome is certain (outside the 2^-48
 //     band) and with the reference's six true divisions otherwise;
 //   * runs the reference's triangle test and t_k computation unchanged.
-// Every other ray falls back to trace_closest().  Per-lane traversal stack: 32 entries in LDS, [depth][lane] layout.
+// Every other ray takes trace_closest().  The walk itself is in trace_persistent.hpp (per-lane stack: 32 entries in LDS).
 #pragma once
 #include "dev_common.hpp"
 
@@ -42,6 +42,13 @@ __device__ __forceinline__ bool slab_may_hit(const Slab& s)
     return s.exit >= 0.0 && s.entry <= s.exit + s.exit * 0x1p-48;
 }
 
+// the reference's box test certainly passes for THIS box (not merely for something inside it): every tmax >= 0 and
+// either every tmin <= 0 or dmax(tmin) <= dmin(tmax) with the rounding band excluded
+__device__ __forceinline__ bool slab_certain_pass(const Slab& s)
+{
+    return s.exit >= 0.0 && (s.entry <= 0.0 || s.entry + s.entry * 0x1p-48 <= s.exit);
+}
+
 // intersect(Ray&, boundingBox&) of the reference on explicit planes (true divisions)
 __device__ __forceinline__ bool box_hit_exact(const double lo[3], const double hi[3], const Ray& r)
 {
@@ -56,89 +63,89 @@ __device__ __forceinline__ bool box_hit_exact(const double lo[3], const double h
     return dmax3(txmin, tymin, tzmin) <= dmin3(txmax, tymax, tzmax);
 }
 
+// Rays the fast walk may take.  fp64 side (exact decisions at the leaves): no under/overflow in (b-o)*(1/d);
+// fp32 side (conservative culling on compressed nodes): every product stays finite and above the denormal range.
 __device__ __forceinline__ bool fast_path_ok(const DFast& F, const Ray& r)
 {
     const double ax = fabs(r.d.x), ay = fabs(r.d.y), az = fabs(r.d.z);
-    const bool d_ok = ax >= 1e-100 && ax <= 1e100 && ay >= 1e-100 && ay <= 1e100 && az >= 1e-100 && az <= 1e100;
+    const bool d_ok = ax >= 1e-15 && ax <= 1e15 && ay >= 1e-15 && ay <= 1e15 && az >= 1e-15 && az <= 1e15;
     const double ox = fabs(r.o.x), oy = fabs(r.o.y), oz = fabs(r.o.z);
-    const bool o_ok = (ox == 0.0 || (ox >= 1e-150 && ox <= 1e150)) && (oy == 0.0 || (oy >= 1e-150 && oy <= 1e150)) &&
-                      (oz == 0.0 || (oz >= 1e-150 && oz <= 1e150));
+    const bool o_ok = (ox == 0.0 || (ox >= 1e-150 && ox <= 1e15)) && (oy == 0.0 || (oy >= 1e-150 && oy <= 1e15)) &&
+                      (oz == 0.0 || (oz >= 1e-150 && oz <= 1e15));
     return F.enabled && d_ok && o_ok;      // NaNs fail every comparison -> false
 }
 
-// stack: LDS words, this lane's slots are stack[i * stride]
-__device__ __forceinline__ bool trace_closest_fast(const DScene& S, const Ray& r, Hit& best, Work& w, int* __restrict__ stack, int stride)
+// Per-ray constants of the conservative fp32 test on compressed nodes.
+// For a plane at p + q*2^e the parametric distance is t(q) = q*(2^e r) + (p - o) r.  Computed in fp32 from
+// o32 = fl(o), r32 = fl(1/d) it differs from the real value by less than 6 eps |r| (|o| + 3S) (S = largest scene
+// coordinate; q*2^e <= 2S, |p| <= S), so subtracting / adding pad = 16 eps |r| (|o| + 3S) gives a rigorous lower bound
+// of the slab entry and upper bound of the slab exit of the decoded box, which itself contains the child's fp64 box.
+struct RayF {
+    float o[3], r[3], pad[3];
+};
+__device__ __forceinline__ RayF make_rayf(const DFast& F, const Ray& ray, const V3& rcp)
 {
-    const DFast& F = S.fast;
-    if (!fast_path_ok(F, r)) return trace_closest(S, r, best, w);
+    RayF f;
+    f.o[0] = (float)ray.o.x; f.o[1] = (float)ray.o.y; f.o[2] = (float)ray.o.z;
+    f.r[0] = (float)rcp.x; f.r[1] = (float)rcp.y; f.r[2] = (float)rcp.z;
+    const double s3 = 3.0 * F.absmax;
+    f.pad[0] = __double2float_ru(16.0 * 0x1p-24 * (fabs(ray.o.x) + s3) * fabs(rcp.x) * 1.0000002);
+    f.pad[1] = __double2float_ru(16.0 * 0x1p-24 * (fabs(ray.o.y) + s3) * fabs(rcp.y) * 1.0000002);
+    f.pad[2] = __double2float_ru(16.0 * 0x1p-24 * (fabs(ray.o.z) + s3) * fabs(rcp.z) * 1.0000002);
+    return f;
+}
 
-    const V3 rcp = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
-    const double dmin = fmin(fmin(fabs(r.d.x), fabs(r.d.y)), fabs(r.d.z));
-    const double scale = fmax(fmax(F.absmax, fabs(r.o.x)), fmax(fabs(r.o.y), fabs(r.o.z)));
-    const double margin = dmin >= 1e-6 ? 1e-9 * scale / dmin : __builtin_inf();
-    const FastNode* __restrict__ nodes = F.nodes;
-    const DTri* __restrict__ tris = F.tris;
+struct CwHits { float key[4]; int ref[4]; };
 
-    bool found = false;
-    best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
-    double limit = __builtin_inf();          // best.t + margin once something is found
-    int sp = 0;
-    int cur = 0;                             // root
-    for (;;) {
-        while (cur >= 0) {                   // inner nodes
-            const FastNode* nd = nodes + cur;
-            w.nodes++;
-            const Slab s0 = slab_interval(nd->lo[0], nd->hi[0], r.o, rcp);
-            const Slab s1 = slab_interval(nd->lo[1], nd->hi[1], r.o, rcp);
-            const int c0 = nd->child[0], c1 = nd->child[1];
-            const bool h0 = c0 != MCPT_FAST_EMPTY && slab_may_hit(s0) && !(s0.entry > limit);
-            const bool h1 = c1 != MCPT_FAST_EMPTY && slab_may_hit(s1) && !(s1.entry > limit);
-            if (h0 && h1) {
-                const bool first0 = s0.entry <= s1.entry;
-                stack[sp * stride] = first0 ? c1 : c0;
-                sp++;
-                cur = first0 ? c0 : c1;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else if (sp > 0) { sp--; cur = stack[sp * stride]; }
-            else cur = MCPT_FAST_EMPTY;
-        }
-        if (cur == MCPT_FAST_EMPTY) break;
-        {                                    // leaf
-            const int ref = -1 - cur;
-            const int first = ref >> 4, count = (ref & 15) + 1;
-            for (int i = 0; i < count; i++) {
-                const DTri* tr = tris + first + i;
-                // the reference's leaf box of this triangle (findBondingBox(Face&), BVH.cpp:87-97)
-                double lo[3], hi[3];
-                lo[0] = dmin3(tr->v1[0], tr->v2[0], tr->v3[0]); hi[0] = dmax3(tr->v1[0], tr->v2[0], tr->v3[0]);
-                lo[1] = dmin3(tr->v1[1], tr->v2[1], tr->v3[1]); hi[1] = dmax3(tr->v1[1], tr->v2[1], tr->v3[1]);
-                lo[2] = dmin3(tr->v1[2], tr->v2[2], tr->v3[2]); hi[2] = dmax3(tr->v1[2], tr->v2[2], tr->v3[2]);
-                const Slab s = slab_interval(lo, hi, r.o, rcp);
-                if (s.exit < 0.0) continue;                                  // a tmax < 0: the sign of a quotient is exact
-                if (s.entry > limit) continue;                               // cannot beat the current best
-                bool pass;
-                if (s.entry <= 0.0) pass = true;                             // every tmin <= 0 (signs exact)
-                else if (s.entry + s.entry * 0x1p-48 <= s.exit) pass = true; // certainly dmax(tmin) <= dmin(tmax)
-                else if (s.entry > s.exit + s.exit * 0x1p-48) pass = false;  // certainly not
-                else pass = box_hit_exact(lo, hi, r);                        // inside the rounding band: ask the reference
-                if (!pass) continue;
-                V3 p;
-                w.tris++;
-                if (tri_hit(tr, r, p)) {
-                    const double t = (p.x - r.o.x) / r.d.x;                  // pathTracing.cpp:347
-                    const int k = tr->leaf;
-                    if (t > 0 && (!found || t < best.t || (t == best.t && k < best.leaf))) {
-                        found = true; best.leaf = k; best.t = t; best.p = p;
-                        limit = t + margin;
-                    }
-                }
-            }
-        }
-        if (sp > 0) { sp--; cur = stack[sp * stride]; }
-        else break;
+// One step on a compressed node: which children may contain a candidate, sorted by lower bound of entry distance
+// (absent / culled children get key = +inf, ref = EMPTY).
+__device__ __forceinline__ CwHits cw_step(const CwNode* __restrict__ nd, const RayF& f, float limit_f)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(nd);
+    const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+    const float p[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+    const int e[3] = {(int)(signed char)(w0.w & 255u), (int)(signed char)((w0.w >> 8) & 255u), (int)(signed char)((w0.w >> 16) & 255u)};
+    const unsigned qlo[3] = {w1.x, w1.y, w1.z}, qhi[3] = {w1.w, w2.x, w2.y};
+    const int child[4] = {(int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y};
+    float sr[3], prlo[3], prhi[3];
+    unsigned nearw[3], farw[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float scale = __uint_as_float((unsigned)(e[a] + 127) << 23);
+        const float prb = (p[a] - f.o[a]) * f.r[a];
+        sr[a] = scale * f.r[a];
+        prlo[a] = prb - f.pad[a];
+        prhi[a] = prb + f.pad[a];
+        const bool pos = f.r[a] >= 0.0f;
+        nearw[a] = pos ? qlo[a] : qhi[a];
+        farw[a] = pos ? qhi[a] : qlo[a];
     }
-    return found;
+    CwHits h;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float tnx = fmaf((float)((nearw[0] >> (8 * c)) & 255u), sr[0], prlo[0]);
+        const float tny = fmaf((float)((nearw[1] >> (8 * c)) & 255u), sr[1], prlo[1]);
+        const float tnz = fmaf((float)((nearw[2] >> (8 * c)) & 255u), sr[2], prlo[2]);
+        const float tfx = fmaf((float)((farw[0] >> (8 * c)) & 255u), sr[0], prhi[0]);
+        const float tfy = fmaf((float)((farw[1] >> (8 * c)) & 255u), sr[1], prhi[1]);
+        const float tfz = fmaf((float)((farw[2] >> (8 * c)) & 255u), sr[2], prhi[2]);
+        const float entry = fmaxf(fmaxf(tnx, tny), tnz);
+        const float exit = fminf(fminf(tfx, tfy), tfz);
+        const bool hit = child[c] != MCPT_FAST_EMPTY && exit >= 0.0f && entry <= exit && entry <= limit_f;
+        h.key[c] = hit ? entry : __builtin_inff();
+        h.ref[c] = hit ? child[c] : MCPT_FAST_EMPTY;
+    }
+    // sorting network for 4 keys
+#define MCPT_CSWAP(i, j)                                                                        \
+    {                                                                                           \
+        const bool sw = h.key[j] < h.key[i];                                                    \
+        const float ka = sw ? h.key[j] : h.key[i], kb = sw ? h.key[i] : h.key[j];               \
+        const int ra = sw ? h.ref[j] : h.ref[i], rb = sw ? h.ref[i] : h.ref[j];                 \
+        h.key[i] = ka; h.key[j] = kb; h.ref[i] = ra; h.ref[j] = rb;                             \
+    }
+    MCPT_CSWAP(0, 1) MCPT_CSWAP(2, 3) MCPT_CSWAP(0, 2) MCPT_CSWAP(1, 3) MCPT_CSWAP(1, 2)
+#undef MCPT_CSWAP
+    return h;
 }
 
 }  // namespace mcpt

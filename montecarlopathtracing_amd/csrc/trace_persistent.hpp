@@ -19,25 +19,54 @@
 
 namespace mcpt {
 
+#ifndef MCPT_REFILL_LANES
 #define MCPT_REFILL_LANES 16        /* refill as soon as this many lanes are idle */
+#endif
+#ifndef MCPT_INNER_BURST
+#define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
+#endif
+
+// 1/x to within a few ulp (v_rcp_f64 + two Newton steps).  Only feeds the conservative culling and the certainty bands
+// (2^-48 relative slack = 32 ulp); every value that reaches an output is computed with true divisions.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
 
 // Src must provide:  long long total() const;
-//                    bool fetch(long long q, Ray& r) const;        // false: slot holds no ray
+//                    bool fetch(long long q, Ray& r) const;        // false: slot holds no ray (loads may be speculative)
 //                    void store(long long q, bool hit, const Hit& h) const;
+//
+// Ray supply is double-buffered so that its memory latency never stalls the lanes that are walking:
+//   stage 1: the next 64 slots of the wave's chunk are loaded into registers (one slot per lane, issued early, not waited for);
+//   stage 2: when the LDS batch is used up, stage 1 is written to LDS ([component][lane], 52 B per ray) and the following
+//            64 slots are requested at once; idle lanes take entries of the LDS batch by ballot rank.
+#define MCPT_RAYBUF_DOUBLES 6
+#define MCPT_RAYBUF_BYTES (64 * (MCPT_RAYBUF_DOUBLES * 8 + 4))      /* per wave */
+
 template <class Src>
 __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src, TraceQueue* queue, long long* __restrict__ slow_list,
-                                                 unsigned int slow_cap, long long chunk, int* __restrict__ stack, int stride, Work& w)
+                                                 unsigned int slow_cap, long long chunk, int* __restrict__ stack, int stride,
+                                                 double* __restrict__ raybuf /* this wave's MCPT_RAYBUF_BYTES of LDS */, Work& w)
 {
     const DFast& F = S.fast;
-    const FastNode* __restrict__ nodes = F.nodes;
+    const CwNode* __restrict__ nodes = F.cw;
     const DTri* __restrict__ tris = F.tris;
     const long long total = src.total();
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int* __restrict__ rayflag = reinterpret_cast<int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
 
-    // wave-uniform range of slots still to hand out
-    long long next = 0, range_end = 0;
-    bool queue_empty = false;
+    // wave-uniform supply state
+    long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk
+    bool queue_empty = false;                   // no more slots anywhere
+    long long reg_base = 0; int reg_count = 0;  // stage 1: slots [reg_base, reg_base+reg_count) in flight / in registers
+    long long lds_base = 0; int lds_count = 0, lds_taken = 0;   // stage 2
+    Ray reg_ray; reg_ray.o = mk(0, 0, 0); reg_ray.d = mk(1, 1, 1);
+    bool reg_valid = false;
 
     // lane state
     enum { ST_IDLE = 0, ST_INNER = 1, ST_TRI = 2 };
@@ -45,41 +74,76 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     long long slot = -1;
     Ray r; r.o = mk(0, 0, 0); r.d = mk(1, 1, 1);
     V3 rcp = mk(1, 1, 1);
+    RayF rf; for (int a = 0; a < 3; a++) { rf.o[a] = 0; rf.r[a] = 1; rf.pad[a] = 0; }
+    float limit_f = 0;
     double margin = 0, limit = 0;
     bool found = false;
     Hit best; best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
     int sp = 0, cur = 0, tri_i = 0, tri_end = 0;
 
+    // claim the next <= 64 slots and issue their loads (stage 1)
+    auto request = [&]() {
+        reg_count = 0;
+        if (queue_empty) return;
+        if (next >= range_end) {
+            unsigned long long got = 0;
+            if (lane == 0) got = atomicAdd(&queue->head, (unsigned long long)chunk);
+            got = __shfl(got, 0, 64);
+            next = (long long)got;
+            range_end = next + chunk < total ? next + chunk : total;
+            if (next >= total) { queue_empty = true; return; }
+        }
+        const long long avail = range_end - next;
+        reg_count = avail < 64 ? (int)avail : 64;
+        reg_base = next;
+        next += reg_count;
+        reg_valid = lane < reg_count && src.fetch(reg_base + lane, reg_ray);
+    };
+    request();
+
+#ifdef MCPT_TRACE_DIAG
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+    int last_phase = 0;
+#define MCPT_STAMP(ph) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) w.diag[5 + last_phase] += t_now - t_prev; t_prev = t_now; last_phase = ph; }
+#else
+#define MCPT_STAMP(ph)
+#endif
     for (;;) {
         // ------------------------------------------------------------------ refill idle lanes
+        MCPT_STAMP(0)
         unsigned long long idle = __ballot(state == ST_IDLE);
-        if (idle && !queue_empty && (__popcll(idle) >= MCPT_REFILL_LANES || idle == ~0ull)) {
-            for (;;) {                                   // until every idle lane has a ray or the queue is dry
+        const bool supply = lds_taken < lds_count || reg_count > 0;
+        if (idle && supply && (__popcll(idle) >= MCPT_REFILL_LANES || idle == ~0ull)) {
+            for (;;) {
                 idle = __ballot(state == ST_IDLE);
                 if (!idle) break;
-                if (next >= range_end) {                 // claim a new chunk (wave-uniform)
-                    unsigned long long got = 0;
-                    if (lane == 0) got = atomicAdd(&queue->head, (unsigned long long)chunk);
-                    got = __shfl(got, 0, 64);
-                    next = (long long)got;
-                    range_end = next + chunk < total ? next + chunk : total;
-                    if (next >= total) { queue_empty = true; break; }
+                if (lds_taken >= lds_count) {            // stage 1 -> stage 2, and ask for the batch after it
+                    if (reg_count == 0) break;           // nothing left anywhere
+                    raybuf[0 * 64 + lane] = reg_ray.o.x; raybuf[1 * 64 + lane] = reg_ray.o.y; raybuf[2 * 64 + lane] = reg_ray.o.z;
+                    raybuf[3 * 64 + lane] = reg_ray.d.x; raybuf[4 * 64 + lane] = reg_ray.d.y; raybuf[5 * 64 + lane] = reg_ray.d.z;
+                    rayflag[lane] = reg_valid ? 1 : 0;
+                    lds_base = reg_base; lds_count = reg_count; lds_taken = 0;
+                    request();
                 }
                 const int want = __popcll(idle);
-                const long long avail = range_end - next;
-                const int give = want < avail ? want : (int)avail;
+                const int avail = lds_count - lds_taken;
+                const int give = want < avail ? want : avail;
                 const int rank = __popcll(idle & lt_mask);
                 if (state == ST_IDLE && rank < give) {
-                    const long long q = next + rank;
-                    Ray nr;
-                    if (src.fetch(q, nr)) {
+                    const int e = lds_taken + rank;
+                    if (rayflag[e]) {
+                        Ray nr;
+                        nr.o = mk(raybuf[0 * 64 + e], raybuf[1 * 64 + e], raybuf[2 * 64 + e]);
+                        nr.d = mk(raybuf[3 * 64 + e], raybuf[4 * 64 + e], raybuf[5 * 64 + e]);
+                        const long long q = lds_base + e;
                         if (fast_path_ok(F, nr)) {
                             slot = q; r = nr;
-                            rcp = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
-                            const double dmin = fmin(fmin(fabs(r.d.x), fabs(r.d.y)), fabs(r.d.z));
+                            rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+                            const double rmax = fmax(fmax(fabs(rcp.x), fabs(rcp.y)), fabs(rcp.z));     // = 1 / min|d_k|
                             const double scale = fmax(fmax(F.absmax, fabs(r.o.x)), fmax(fabs(r.o.y), fabs(r.o.z)));
-                            margin = dmin >= 1e-6 ? 1e-9 * scale / dmin : __builtin_inf();
-                            limit = __builtin_inf();
+                            margin = rmax <= 1e6 ? 1.0000001e-9 * scale * rmax : __builtin_inf();
+                            limit = __builtin_inf(); limit_f = __builtin_inff();
+                            rf = make_rayf(F, r, rcp);
                             found = false; best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
                             sp = 0; cur = 0; state = ST_INNER;
                         } else {
@@ -88,56 +152,59 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                         }
                     }
                 }
-                next += give;
+                lds_taken += give;
             }
         }
         // ------------------------------------------------------------------ pick the phase most lanes wait for
         const unsigned long long m_inner = __ballot(state == ST_INNER);
         const unsigned long long m_tri = __ballot(state == ST_TRI);
         if (!m_inner && !m_tri) {
-            if (queue_empty) break;
-            continue;                                    // everyone idle but the queue is not dry: refill next round
+            if (lds_taken >= lds_count && reg_count == 0) break;      // no walking lane and no ray left to hand out
+            continue;
         }
+#ifdef MCPT_TRACE_DIAG
+        if (lane == 0) {
+            const bool in = __popcll(m_inner) >= __popcll(m_tri);
+            w.diag[in ? 0 : 2] += 1; w.diag[in ? 1 : 3] += in ? __popcll(m_inner) : __popcll(m_tri);
+            w.diag[4] += 64 - __popcll(m_inner) - __popcll(m_tri);
+        }
+#endif
+        MCPT_STAMP(__popcll(m_inner) >= __popcll(m_tri) ? 1 : 2)
         if (__popcll(m_inner) >= __popcll(m_tri)) {
-            // -------------------------------------------------------------- one inner step
+            // -------------------------------------------------------------- inner steps (a short burst per vote)
+#pragma unroll 1
+            for (int burst = 0; burst < MCPT_INNER_BURST; burst++)
             if (state == ST_INNER) {
-                const FastNode* nd = nodes + cur;
                 w.nodes++;
-                const Slab s0 = slab_interval(nd->lo[0], nd->hi[0], r.o, rcp);
-                const Slab s1 = slab_interval(nd->lo[1], nd->hi[1], r.o, rcp);
-                const int c0 = nd->child[0], c1 = nd->child[1];
-                const bool h0 = c0 != MCPT_FAST_EMPTY && slab_may_hit(s0) && !(s0.entry > limit);
-                const bool h1 = c1 != MCPT_FAST_EMPTY && slab_may_hit(s1) && !(s1.entry > limit);
-                int nxt;
-                if (h0 && h1) {
-                    const bool first0 = s0.entry <= s1.entry;
-                    stack[sp * stride] = first0 ? c1 : c0;
-                    sp++;
-                    nxt = first0 ? c0 : c1;
-                } else if (h0) nxt = c0;
-                else if (h1) nxt = c1;
-                else if (sp > 0) { sp--; nxt = stack[sp * stride]; }
-                else nxt = MCPT_FAST_EMPTY;
+                const CwHits h = cw_step(nodes + cur, rf, limit_f);
+                // nearest first; the others go on the stack so that the next nearest is on top
+                if (h.ref[3] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[3]; sp++; }
+                if (h.ref[2] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[2]; sp++; }
+                if (h.ref[1] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[1]; sp++; }
+                int nxt = h.ref[0];
+                if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = stack[sp * stride]; }
                 if (nxt >= 0) cur = nxt;
                 else if (nxt == MCPT_FAST_EMPTY) { src.store(slot, found, best); state = ST_IDLE; }
-                else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 15) + 1; state = ST_TRI; }
+                else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; state = ST_TRI; }
             }
         } else {
             // -------------------------------------------------------------- one triangle of the current leaf
             if (state == ST_TRI) {
                 const DTri* tr = tris + tri_i;
                 tri_i++;
-                double lo[3], hi[3];
-                lo[0] = dmin3(tr->v1[0], tr->v2[0], tr->v3[0]); hi[0] = dmax3(tr->v1[0], tr->v2[0], tr->v3[0]);
-                lo[1] = dmin3(tr->v1[1], tr->v2[1], tr->v3[1]); hi[1] = dmax3(tr->v1[1], tr->v2[1], tr->v3[1]);
-                lo[2] = dmin3(tr->v1[2], tr->v2[2], tr->v3[2]); hi[2] = dmax3(tr->v1[2], tr->v2[2], tr->v3[2]);
-                const Slab s = slab_interval(lo, hi, r.o, rcp);
                 bool pass = false;
-                if (!(s.exit < 0.0) && !(s.entry > limit)) {
-                    if (s.entry <= 0.0) pass = true;
-                    else if (s.entry + s.entry * 0x1p-48 <= s.exit) pass = true;
-                    else if (s.entry > s.exit + s.exit * 0x1p-48) pass = false;
-                    else pass = box_hit_exact(lo, hi, r);
+                {
+                    double lo[3], hi[3];
+                    lo[0] = dmin3(tr->v1[0], tr->v2[0], tr->v3[0]); hi[0] = dmax3(tr->v1[0], tr->v2[0], tr->v3[0]);
+                    lo[1] = dmin3(tr->v1[1], tr->v2[1], tr->v3[1]); hi[1] = dmax3(tr->v1[1], tr->v2[1], tr->v3[1]);
+                    lo[2] = dmin3(tr->v1[2], tr->v2[2], tr->v3[2]); hi[2] = dmax3(tr->v1[2], tr->v2[2], tr->v3[2]);
+                    const Slab s = slab_interval(lo, hi, r.o, rcp);
+                    if (!(s.exit < 0.0) && !(s.entry > limit)) {
+                        if (s.entry <= 0.0) pass = true;
+                        else if (s.entry + s.entry * 0x1p-48 <= s.exit) pass = true;
+                        else if (s.entry > s.exit + s.exit * 0x1p-48) pass = false;
+                        else pass = box_hit_exact(lo, hi, r);
+                    }
                 }
                 if (pass) {
                     V3 p;
@@ -148,6 +215,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                         if (t > 0 && (!found || t < best.t || (t == best.t && k < best.leaf))) {
                             found = true; best.leaf = k; best.t = t; best.p = p;
                             limit = t + margin;
+                            limit_f = __double2float_ru(limit);
                         }
                     }
                 }
@@ -156,7 +224,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                         sp--;
                         const int nxt = stack[sp * stride];
                         if (nxt >= 0) { cur = nxt; state = ST_INNER; }
-                        else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 15) + 1; }
+                        else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
                     } else { src.store(slot, found, best); state = ST_IDLE; }
                 }
             }

@@ -8,6 +8,10 @@
 
 namespace mcpt {
 
+#ifndef MCPT_LOGIC_WAVES
+#define MCPT_LOGIC_WAVES 3   /* waves per SIMD the logic kernel is compiled for */
+#endif
+
 // ---------------------------------------------------------------------------------------------- layout helpers
 __device__ __forceinline__ V3 ldc(const double* __restrict__ a, long long cap, long long i)
 {
@@ -47,7 +51,7 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfSta
 // ---------------------------------------------------------------------------------------------- logic kernel
 // One thread per path position of the previous iteration.  FIRST: positions enumerate (hit slot, k).
 template <bool FIRST>
-__global__ void __launch_bounds__(256) k_wf_logic(DScene S, WfArgs a, long long n_prev)
+__global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a, long long n_prev)
 {
     __shared__ unsigned int wave_tot[4];
     __shared__ unsigned int block_base;
@@ -254,20 +258,26 @@ struct WfRaySource {
     WfArgs a;
     long long n_paths;
     __device__ __forceinline__ long long total() const { return n_paths * (a.nl + 1); }
+    // (l, j) of slot q without a 64-bit division: nl is small
+    __device__ __forceinline__ void split(long long q, int& l, long long& j) const
+    {
+        l = 0; j = q;
+        while (j >= n_paths) { j -= n_paths; l++; }
+    }
     __device__ __forceinline__ bool fetch(long long q, Ray& r) const
     {
-        const int l = (int)(q / n_paths);
-        const long long j = q - (long long)l * n_paths;
-        const bool valid = l == a.nl ? a.out.btype[j] >= 0 : a.out.expect[(long long)l * a.cap + j] != -2;
-        if (!valid) return false;
+        int l; long long j;
+        split(q, l, j);
+        // branch-free: the ray words are loaded whether or not the slot is in use, so nothing waits on the flag
+        const int flag = l == a.nl ? a.out.btype[j] : a.out.expect[(long long)l * a.cap + j];
         r.o = ldc(a.rays.o + (long long)l * 3 * a.cap, a.cap, j);
         r.d = ldc(a.rays.d + (long long)l * 3 * a.cap, a.cap, j);
-        return true;
+        return l == a.nl ? flag >= 0 : flag != -2;
     }
     __device__ __forceinline__ void store(long long q, bool ok, const Hit& h) const
     {
-        const int l = (int)(q / n_paths);
-        const long long j = q - (long long)l * n_paths;
+        int l; long long j;
+        split(q, l, j);
         if (l == a.nl) {
             a.out.hit_leaf[j] = ok ? h.leaf : -1;
             if (ok) stc(a.out.hit_p, a.cap, j, h.p);
@@ -282,11 +292,15 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfArgs a, long long 
                                                   unsigned int slow_cap, long long chunk)
 {
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
+    __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, w);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w);
     ls.nodes = w.nodes; ls.tris = w.tris;
+#ifdef MCPT_TRACE_DIAG
+    if ((threadIdx.x & 63) == 0 && a.ctr) for (int i = 0; i < 8; i++) atomicAdd(&a.ctr->pad[i], w.diag[i]);
+#endif
     flush_stats(a.ctr, ls);
 }
 
