@@ -171,7 +171,7 @@ __device__ void shade_path(const DScene& S, const RngKey& key, V3 view_dir /* ra
         }
         const V3 tv1 = ld3(tr->v1), tv2 = ld3(tr->v2), tv3 = ld3(tr->v3);
         const DTriShade* sh = S.shade + hit.leaf;
-        const V3 g = barycentric(tv1, tv2, tv3, hit.p);
+        const V3 g = barycentric_s(tv1, tv2, tv3, hit.p);
         const V3 pn = (ld3(sh->vn1) * g.x + ld3(sh->vn2) * g.y) + ld3(sh->vn3) * g.z;
         V3 kd;
         if (m->has_map) {                                                       // :147-160 (Q9)
@@ -182,7 +182,7 @@ __device__ void shade_path(const DScene& S, const RngKey& key, V3 view_dir /* ra
             rr = rr < 0 ? 0 : (rr > m->map_h - 1 ? m->map_h - 1 : rr);          // D7
             cc = cc < 0 ? 0 : (cc > m->map_w - 1 ? m->map_w - 1 : cc);
             const uint8_t* px = S.texels + m->tex_offset + ((size_t)rr * m->map_w + cc) * 3;
-            kd = mk((double)px[2] / 255, (double)px[1] / 255, (double)px[0] / 255);
+            kd = mk((double)px[2] * MCPT_INV_255, (double)px[1] * MCPT_INV_255, (double)px[0] * MCPT_INV_255);
         } else kd = ld3(m->kd);
 
         // direct illumination, :166-232
@@ -200,11 +200,12 @@ __device__ void shade_path(const DScene& S, const RngKey& key, V3 view_dir /* ra
                 const DLightTri* q = S.light_tris + lt->first + j;
                 sample_mat = lt->material;
                 const double rnd1 = u1, rnd2 = u2, rnd3 = u3;
-                const double p1 = rnd1 / (rnd1 + rnd2 + rnd3), p2 = rnd2 / (rnd1 + rnd2 + rnd3), p3 = rnd3 / (rnd1 + rnd2 + rnd3);
+                const double isum = frcp(rnd1 + rnd2 + rnd3);
+                const double p1 = rnd1 * isum, p2 = rnd2 * isum, p3 = rnd3 * isum;
                 xl = (ld3(q->v1) * p1 + ld3(q->v2) * p2) + ld3(q->v3) * p3;
                 vn = (ld3(q->vn1) * p1 + ld3(q->vn2) * p2) + ld3(q->vn3) * p3;
             }
-            const V3 direction = normalized(xl - hit.p);
+            const V3 direction = normalized_s(xl - hit.p);
             double visibility = 1;
             Ray rl; rl.o = hit.p + direction * 0.01; rl.d = direction;
             Hit inter;
@@ -213,17 +214,16 @@ __device__ void shade_path(const DScene& S, const RngKey& key, V3 view_dir /* ra
             const int inter_mat = got ? S.tris[inter.leaf].material : -1;
             if (inter_mat != sample_mat) visibility = 0;                        // :213
             if (dot(direction, pn) > 0) {
-                const double pdf_light = (double)1 / lt->total_area;
-                const double cos_theta = fabs(dot(direction, vn) / norm(direction) / norm(vn));
-                const double cos_theta_hat = fabs(dot(direction, pn) / norm(direction) / norm(pn));
+                                const double cos_theta = fabs(dot(direction, vn) * frcp(norm(direction)) * frcp(norm(vn)));
+                const double cos_theta_hat = fabs(dot(direction, pn) * frcp(norm(direction)) * frcp(norm(pn)));
                 const double dd = norm(xl - hit.p);
                 const double dist = (1.0 < dd) ? dd : 1.0;                      // std::max(1.0, distance)
-                const V3 intensity = ((((ld3(lt->radiance) * cos_theta) * cos_theta_hat) / pow(dist, 2.0)) / pdf_light) * visibility;
+                const V3 intensity = (((ld3(lt->radiance) * cos_theta) * cos_theta_hat) * (frcp(sqr(dist)) * lt->total_area)) * visibility;
                 const double kd_dots = dot(direction, pn);
                 if (kd_dots > 0) {
-                    L_dir.x += kd.x * intensity.x * kd_dots / MCPT_PI;
-                    L_dir.y += kd.y * intensity.y * kd_dots / MCPT_PI;
-                    L_dir.z += kd.z * intensity.z * kd_dots / MCPT_PI;
+                    L_dir.x += kd.x * intensity.x * kd_dots * MCPT_INV_PI;
+                    L_dir.y += kd.y * intensity.y * kd_dots * MCPT_INV_PI;
+                    L_dir.z += kd.z * intensity.z * kd_dots * MCPT_INV_PI;
                 }
             }
         }
@@ -243,8 +243,8 @@ __device__ void shade_path(const DScene& S, const RngKey& key, V3 view_dir /* ra
             V3 normal;
             if (cos_in > 0) { normal = neg(pn); n1 = m->Ni; n2 = 1.0; }
             else { normal = pn; n1 = 1.0; n2 = m->Ni; }
-            const double rf0 = pow((n1 - n2) / (n1 + n2), 2.0);
-            const double fresnel = rf0 + (1.0f - rf0) * pow(1.0f - fabs(cos_in), 5.0);
+            const double rf0 = sqr((n1 - n2) / (n1 + n2));
+            const double fresnel = rf0 + (1.0f - rf0) * pow5(1.0f - fabs(cos_in));
             if (fresnel < u_fresnel) {
                 V3 direction;
                 if (refract_dir(neg(dir), normal, n1 / n2, direction)) { nr.o = hit.p; nr.d = direction; type = RT_TRANSMISSION; }
@@ -275,7 +275,7 @@ __device__ void shade_path(const DScene& S, const RngKey& key, V3 view_dir /* ra
         ls.bounce++;
         if (!trace_closest(S, nr, next, w)) break;
         const V3 wgt = type == RT_DIFFUSE ? kd : (type == RT_SPECULAR ? ks : mk(1, 1, 1));
-        T = mk(T.x * wgt.x / MCPT_P_RR, T.y * wgt.y / MCPT_P_RR, T.z * wgt.z / MCPT_P_RR);
+        T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
         hit = next; dir = neg(nr.d); in_type = type;
     }
     ls.nodes += w.nodes; ls.tris += w.tris;

@@ -60,8 +60,17 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
     const uint32_t depth = (uint32_t)a.depth;           // depth of the vertex shaded in this pass
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     LaneStats ls;
+#ifdef MCPT_TRACE_DIAG
+    unsigned long long dg[4] = {0, 0, 0, 0};
+#define MCPT_LSTAMP(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); dg[k] += tn - tl; tl = tn; }
+#else
+#define MCPT_LSTAMP(k)
+#endif
     const long long n_round = (n_prev + 255) / 256 * 256;
     for (long long base = (long long)blockIdx.x * 256; base < n_round; base += (long long)gridDim.x * 256) {
+#ifdef MCPT_TRACE_DIAG
+        unsigned long long tl = __builtin_amdgcn_s_memtime();
+#endif
         const long long i = base + threadIdx.x;
         bool alive = false;
         int id = 0, leaf = -1, in_type = RT_TRANSMISSION;
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                     const int hl = a.in.hit_leaf[i];
                     if (hl >= 0) {
                         const V3 wgt = ldc(a.in.w, cap, i);
-                        T = mk(T.x * wgt.x / MCPT_P_RR, T.y * wgt.y / MCPT_P_RR, T.z * wgt.z / MCPT_P_RR);
+                        T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
                         leaf = hl; p = ldc(a.in.hit_p, cap, i);
                         dir = neg(ldc(a.in.bdir, cap, i));
                         in_type = bt;
@@ -119,6 +128,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             }
             if (!alive) { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; }
         }
+        MCPT_LSTAMP(0)
         // ---- compaction: wave ballot + prefix, one atomic per block
         const unsigned long long bal = __ballot(alive);
         const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -132,6 +142,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         unsigned int off = block_base + before;
         for (int q = 0; q < wv; q++) off += wave_tot[q];
         __syncthreads();
+        MCPT_LSTAMP(1)
         if (!alive) continue;
         const long long j = off;
 
@@ -139,7 +150,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         const DTri* tr = S.tris + leaf;
         const DMaterial* m = S.materials + tr->material;
         const DTriShade* sh = S.shade + leaf;
-        const V3 g = barycentric(ld3(tr->v1), ld3(tr->v2), ld3(tr->v3), p);
+        const V3 g = barycentric_s(ld3(tr->v1), ld3(tr->v2), ld3(tr->v3), p);
         const V3 pn = (ld3(sh->vn1) * g.x + ld3(sh->vn2) * g.y) + ld3(sh->vn3) * g.z;
         V3 kd;
         if (m->has_map) {
@@ -150,7 +161,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             rr = rr < 0 ? 0 : (rr > m->map_h - 1 ? m->map_h - 1 : rr);
             cc = cc < 0 ? 0 : (cc > m->map_w - 1 ? m->map_w - 1 : cc);
             const uint8_t* px = S.texels + m->tex_offset + ((size_t)rr * m->map_w + cc) * 3;
-            kd = mk((double)px[2] / 255, (double)px[1] / 255, (double)px[0] / 255);
+            kd = mk((double)px[2] * MCPT_INV_255, (double)px[1] * MCPT_INV_255, (double)px[0] * MCPT_INV_255);
         } else kd = ld3(m->kd);
 
         const int slot = a.first_slot + id / a.spp;
@@ -170,21 +181,21 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                 uniform2(key, depth, 2u * l + 1u, u2, u3);
                 const DLightTri* q = S.light_tris + lt->first + jt;
                 sample_mat = lt->material;
-                const double p1 = u1 / (u1 + u2 + u3), p2 = u2 / (u1 + u2 + u3), p3 = u3 / (u1 + u2 + u3);
+                const double isum = frcp(u1 + u2 + u3);
+                const double p1 = u1 * isum, p2 = u2 * isum, p3 = u3 * isum;
                 xl = (ld3(q->v1) * p1 + ld3(q->v2) * p2) + ld3(q->v3) * p3;
                 vn = (ld3(q->vn1) * p1 + ld3(q->vn2) * p2) + ld3(q->vn3) * p3;
             }
-            const V3 direction = normalized(xl - p);
+            const V3 direction = normalized_s(xl - p);
             const double kd_dots = dot(direction, pn);
             int expect = -2;
             if (kd_dots > 0) {                                                   // the only case in which the shadow ray's answer is used
-                const double pdf_light = (double)1 / lt->total_area;
-                const double cos_theta = fabs(dot(direction, vn) / norm(direction) / norm(vn));
-                const double cos_theta_hat = fabs(dot(direction, pn) / norm(direction) / norm(pn));
+                                const double cos_theta = fabs(dot(direction, vn) * frcp(norm(direction)) * frcp(norm(vn)));
+                const double cos_theta_hat = fabs(dot(direction, pn) * frcp(norm(direction)) * frcp(norm(pn)));
                 const double dd = norm(xl - p);
                 const double dist = (1.0 < dd) ? dd : 1.0;
-                const V3 intensity = ((((ld3(lt->radiance) * cos_theta) * cos_theta_hat) / pow(dist, 2.0)) / pdf_light) * 1.0;
-                const V3 c = mk(kd.x * intensity.x * kd_dots / MCPT_PI, kd.y * intensity.y * kd_dots / MCPT_PI, kd.z * intensity.z * kd_dots / MCPT_PI);
+                const V3 intensity = ((ld3(lt->radiance) * cos_theta) * cos_theta_hat) * (frcp(sqr(dist)) * lt->total_area);
+                const V3 c = mk(kd.x * intensity.x * kd_dots * MCPT_INV_PI, kd.y * intensity.y * kd_dots * MCPT_INV_PI, kd.z * intensity.z * kd_dots * MCPT_INV_PI);
                 stc(a.out.c + (long long)l * 3 * cap, cap, j, c);
                 stc(a.rays.o + (long long)l * 3 * cap, cap, j, p + direction * 0.01);
                 stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);
@@ -208,8 +219,8 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                     V3 normal;
                     if (cos_in > 0) { normal = neg(pn); n1 = m->Ni; n2 = 1.0; }
                     else { normal = pn; n1 = 1.0; n2 = m->Ni; }
-                    const double rf0 = pow((n1 - n2) / (n1 + n2), 2.0);
-                    const double fresnel = rf0 + (1.0f - rf0) * pow(1.0f - fabs(cos_in), 5.0);
+                    const double rf0 = sqr((n1 - n2) / (n1 + n2));
+                    const double fresnel = rf0 + (1.0f - rf0) * pow5(1.0f - fabs(cos_in));
                     if (fresnel < u_fresnel) {
                         V3 direction;
                         if (refract_dir(neg(dir), normal, n1 / n2, direction)) { nr.o = p; nr.d = direction; btype = RT_TRANSMISSION; }
@@ -248,7 +259,11 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         stc(a.out.w, cap, j, wgt);
         stc(a.out.T, cap, j, T);
         stc(a.out.L, cap, j, L);
+        MCPT_LSTAMP(2)
     }
+#ifdef MCPT_TRACE_DIAG
+    if ((threadIdx.x & 63) == 0 && a.ctr) { for (int k = 0; k < 3; k++) atomicAdd(&a.ctr->pad[8 + k], dg[k]); atomicAdd(&a.ctr->pad[11], 1ull); }
+#endif
     flush_stats(a.ctr, ls);
 }
 
