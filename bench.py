@@ -19,8 +19,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic bytes per unit of work (DESIGN.md "Roofline"): what one ray query must read/write at minimum
-BYTES_PER_NODE = 48      # 6 fp64 box planes of a visited node
-BYTES_PER_TRI = 104      # 9 fp64 vertices + 3 fp64 normal + material/face ids of a tested triangle
+BYTES_PER_NODE = 64      # one compressed 4-wide node (quantised child boxes + child references) per inner step
+BYTES_PER_TRI = 104      # 9 fp64 vertices + 3 fp64 normal + ids of a tested triangle
 BYTES_PER_RAY = 64       # ray origin/direction in, hit record out
 BYTES_PER_SAMPLE = 48    # 24 B radiance written by the shading kernel + 24 B read back by the fold
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -210,7 +210,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches": tot["launches"],
                          "algorithmic_bytes_per_launch": alg_bytes_rank0 / n_launch,
-                         "note": "rank-0 launches; bytes = 48 B x node visits + 104 B x triangle tests + 64 B x rays + 48 B x samples, from the run's own device counters; the scene (2 MB of nodes, 2 MB of triangles) is L2-resident, see DESIGN.md"},
+                         "note": "rank-0 launches; bytes = 64 B x node visits + 104 B x triangle tests + 64 B x rays + 48 B x samples, from the run's own device counters; the scene (0.3 MB of nodes, 2 MB of triangles) is cache-resident, see DESIGN.md"},
         }
         if args.save_png and frame is not None:
             img = frame.cpu().numpy()

@@ -69,7 +69,7 @@ struct PrimaryRaySource {
 };
 
 template <class Src>
-__global__ void __launch_bounds__(256) k_trace_persistent(DScene S, Src src, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
+__global__ void __launch_bounds__(256, 3) k_trace_persistent(DScene S, Src src, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
                                                           long long chunk, DCounters* ctr)
 {
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];

@@ -303,7 +303,7 @@ struct WfRaySource {
 };
 
 // persistent fast walk
-__global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfArgs a, long long n_paths, TraceQueue* queue, long long* slow_list,
+__global__ void __launch_bounds__(256, 3) k_wf_trace(DScene S, WfArgs a, long long n_paths, TraceQueue* queue, long long* slow_list,
                                                   unsigned int slow_cap, long long chunk)
 {
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
