@@ -141,6 +141,10 @@ int  mcpt_quantize_rgb8(const double* img, int64_t n, uint8_t* rgb8);        /* 
 int  mcpt_write_png(const char* file, const uint8_t* rgb8, int32_t width, int32_t height);
 int64_t mcpt_png_encode(const uint8_t* rgb8, int32_t width, int32_t height, uint8_t* out, int64_t cap);
 
+/* Texture input (what the reference gets from cv::imread, MTPC/sceneManagement.h:137): decodes a baseline or progressive
+ * JFIF file into an 8-bit BGR raster (rows x cols x 3).  With bgr == NULL only the size is returned. */
+int  mcpt_decode_jpeg(const char* file, int32_t* width, int32_t* height, uint8_t* bgr, int64_t cap);
+
 /* ---- whole program (render_scene) ---- */
 /* Reads <path><filename>.*, renders with N samples per pixel on GPU 0 and writes
  * "../result/<filename>-SPP<N>.png" relative to the cwd, like the reference. */

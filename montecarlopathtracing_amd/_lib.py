@@ -61,7 +61,7 @@ EXPORTS = [
     "mcpt_device_create", "mcpt_device_free", "mcpt_device_set_trace_mode",
     "mcpt_trace_closest", "mcpt_trace_closest_device",
     "mcpt_render", "mcpt_render_device", "mcpt_sample_radiance", "mcpt_owned_pixels",
-    "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode",
+    "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_decode_jpeg",
     "mcpt_render_scene", "mcpt_render_scene_ex",
 ]
 
@@ -116,6 +116,7 @@ def lib():
     L.mcpt_write_png.argtypes = [C.c_char_p, U8, C.c_int32, C.c_int32]
     L.mcpt_png_encode.restype = C.c_int64
     L.mcpt_png_encode.argtypes = [U8, C.c_int32, C.c_int32, U8, C.c_int64]
+    L.mcpt_decode_jpeg.argtypes = [C.c_char_p, I32, I32, U8, C.c_int64]
     L.mcpt_render_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     L.mcpt_render_scene_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(RenderSceneOptions), C.POINTER(Stats)]
     _lib = L

@@ -190,6 +190,16 @@ def write_png(file, rgb8):
     check(lib().mcpt_write_png(file.encode(), _p(rgb8, C.c_uint8), w, h))
 
 
+def decode_jpeg(file):
+    """8-bit BGR raster [rows, cols, 3] of a JPEG file, as cv::imread would hand it to Material::readinMap."""
+    w = np.zeros(1, dtype=np.int32)
+    h = np.zeros(1, dtype=np.int32)
+    check(lib().mcpt_decode_jpeg(file.encode(), _p(w, C.c_int32), _p(h, C.c_int32), None, 0))
+    out = np.zeros((int(h[0]), int(w[0]), 3), dtype=np.uint8)
+    check(lib().mcpt_decode_jpeg(file.encode(), _p(w, C.c_int32), _p(h, C.c_int32), _p(out, C.c_uint8), out.size))
+    return out
+
+
 def morton_code(x, y, z):
     return lib().mcpt_morton_code(x, y, z)
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "accel_build.hpp"
+#include "jpeg_decoder.hpp"
 #include "kernels.hpp"
 #include "scene.hpp"
 #include "wavefront.hpp"
@@ -798,6 +799,21 @@ int mcpt_write_png(const char* file, const uint8_t* rgb8, int32_t w, int32_t h)
     const bool ok = std::fwrite(buf.data(), 1, size_t(n), fp) == size_t(n);
     std::fclose(fp);                              // the reference never closes it (truncated veach-mis PNGs)
     return ok ? MCPT_OK : fail(MCPT_ERR_IO, std::string("short write to ") + file);
+}
+
+int mcpt_decode_jpeg(const char* file, int32_t* width, int32_t* height, uint8_t* bgr, int64_t cap)
+{
+    if (!file || !width || !height) return fail(MCPT_ERR_ARG, "null argument");
+    int w = 0, h = 0;
+    std::vector<uint8_t> px;
+    std::string err;
+    if (!decode_jpeg_file(file, w, h, px, err)) return fail(MCPT_ERR_IO, err);
+    *width = w; *height = h;
+    if (bgr) {
+        if (cap < int64_t(px.size())) return fail(MCPT_ERR_ARG, "buffer too small");
+        std::memcpy(bgr, px.data(), px.size());
+    }
+    return MCPT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ render_scene

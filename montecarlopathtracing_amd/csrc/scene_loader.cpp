@@ -75,18 +75,21 @@ bool read_ppm(const std::string& file, int& w, int& h, std::vector<uint8_t>& bgr
 }
 
 // Material::readinMap (sceneManagement.h:134-143): cv::imread -> 8-bit BGR raster.
-// Order: "<dir>/<name>.ppm" (pre-decoded raster), "<dir>/<name>" decoded by the built-in JPEG/PPM
-// reader, then the same two relative to the cwd.
+// The file named by map_Kd is read with the built-in decoders (JPEG by jpeg_decoder.cpp, binary PPM); it is looked up
+// next to the scene first, then relative to the cwd (the reference: cwd only).  A "<name>.ppm" raster is accepted as a
+// stand-in for formats that are not built in (PNG, BMP, ...).
 bool load_texture(const std::string& dir, const std::string& name, MaterialRec& m, std::string& err)
 {
     const std::string bases[2] = {dir + name, name};
+    std::string why;
     for (const std::string& b : bases) {
-        if (read_ppm(b + ".ppm", m.map_w, m.map_h, m.bgr)) return true;
-        if (read_ppm(b, m.map_w, m.map_h, m.bgr)) return true;
         std::string jerr;
         if (decode_jpeg_file(b, m.map_w, m.map_h, m.bgr, jerr)) return true;
+        if (why.empty() && jerr.rfind("cannot open", 0) != 0) why = " (" + jerr + ")";
+        if (read_ppm(b, m.map_w, m.map_h, m.bgr)) return true;
+        if (read_ppm(b + ".ppm", m.map_w, m.map_h, m.bgr)) return true;
     }
-    err = "cannot read texture '" + name + "' (looked for " + bases[0] + "[.ppm] and ./" + name + "[.ppm])";
+    err = "cannot read texture '" + name + "' next to the scene or in the cwd" + why;
     return false;
 }
 

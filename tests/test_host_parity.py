@@ -196,3 +196,55 @@ def test_crlf_and_quirky_faces(mcpt, oracle, tmp_path):
     # third corner "7/8/12": vn index "8" has one digit -> vt index atoi("1") = 1 -> vt[0]
     assert g[0, 22] == 0.0 and g[0, 23] == 1.0
     assert sc.light(0)[0] == "L" and np.array_equal(sc.light(0)[1], [3, 2, 1])
+
+
+def test_jpeg_decoder_reproduces_the_shipped_texture(mcpt):
+    """map_Kd cherry-wood-texture.jpg (progressive 4:4:4, what cv::imread decodes in the reference) against the raster
+    decoded by libjpeg (Pillow) committed next to it; the oracle reads that raster."""
+    bgr = mcpt.decode_jpeg(SCENES + "cherry-wood-texture.jpg")
+    raw = open(SCENES + "cherry-wood-texture.jpg.ppm", "rb").read()
+    assert raw.startswith(b"P6\n612 408\n255\n")
+    rgb = np.frombuffer(raw[len(b"P6\n612 408\n255\n"):], dtype=np.uint8).reshape(408, 612, 3)
+    assert bgr.shape == (408, 612, 3)
+    assert np.array_equal(bgr[:, :, ::-1], rgb)
+
+
+def test_jpeg_decoder_against_libjpeg_variants(mcpt, tmp_path):
+    """Baseline / progressive x 4:4:4 / 4:2:2 / 4:2:0 x odd sizes x grayscale x restart intervals, bit-exact with libjpeg."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(0)
+    y, x = np.mgrid[0:77, 0:131]
+    smooth = np.stack([(x * 3 + y) % 256, (x * y) % 256, (128 + 60 * np.sin(x / 7.0) + 40 * np.cos(y / 5.0)).clip(0, 255)], -1).astype(np.uint8)
+    noise = rng.integers(0, 256, size=(50, 67, 3), dtype=np.uint8)
+    n = 0
+    for im in (smooth, noise, smooth[:9, :17], noise[:1, :1]):
+        for prog in (False, True):
+            for sub in (0, 1, 2):
+                for extra in ({}, {"restart_marker_blocks": 3}):
+                    f = str(tmp_path / "t.jpg")
+                    try:
+                        PIL.fromarray(im).save(f, "JPEG", quality=85, progressive=prog, subsampling=sub, **extra)
+                    except TypeError:
+                        continue
+                    want = np.array(PIL.open(f).convert("RGB"))[:, :, ::-1]
+                    assert np.array_equal(mcpt.decode_jpeg(f), want), (im.shape, prog, sub, extra)
+                    n += 1
+    f = str(tmp_path / "g.jpg")
+    PIL.fromarray(smooth[:, :, 0]).save(f, "JPEG", quality=90)
+    assert np.array_equal(mcpt.decode_jpeg(f), np.array(PIL.open(f).convert("RGB"))[:, :, ::-1])
+    assert n >= 24
+
+
+def test_scene_loads_from_the_jpeg_alone(mcpt, oracle, tmp_path):
+    """A user's scene directory holds the .jpg only (no pre-decoded raster): same scene as with the raster."""
+    import shutil
+    for f in ("cornell-box.obj", "cornell-box.mtl", "cornell-box.camera", "cherry-wood-texture.jpg"):
+        shutil.copy(SCENES + f, tmp_path / f)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)           # nothing to find in the cwd either
+    try:
+        sc = mcpt.Scene(str(tmp_path) + os.sep, "cornell-box")
+    finally:
+        os.chdir(cwd)
+    name, rec, fl = sc.material(6)
+    assert name == "Table" and list(fl[:3]) == [1, 612, 408]
