@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-png", default=None)
+    ap.add_argument("--tris", type=int, default=10_000_000, help="--scene synthetic: number of lattice triangles")
     args = ap.parse_args()
 
     import torch
@@ -145,9 +146,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
 
-    scene_dir = write_scene_dir(args.scene, args.width, args.height)
-    scene = M.Scene(scene_dir, args.scene)
-    dev = M.Device(scene, local_rank)
+    if args.scene == "synthetic":
+        from montecarlopathtracing_amd import synthetic
+        t_gen = time.perf_counter()
+        scene = synthetic.make_scene(M, args.tris, defer_build=True, width=args.width, height=args.height)
+        t_dev = time.perf_counter()
+        dev = M.Device(scene, local_rank)          # Morton + sort + BVH levels on the GPU, SAH hierarchy on the host
+        if rank == 0:
+            print("synthetic scene: %d triangles, generate+create %.1f s, device build %.1f s" %
+                  (scene.info.num_faces, t_dev - t_gen, time.perf_counter() - t_dev), file=sys.stderr)
+        scene_dir = None
+    else:
+        scene_dir = write_scene_dir(args.scene, args.width, args.height)
+        scene = M.Scene(scene_dir, args.scene)
+        dev = M.Device(scene, local_rank)
     rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev)
 
     def sync():
@@ -200,7 +212,8 @@ def main():
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec_per_frame * 1e3, "sec_per_frame": sec_per_frame, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "reference scene %s.obj (in repo under scenes/), .camera rewritten to %dx%d, seed %d" % (args.scene, args.width, args.height, args.seed),
+            "data": ("reference scene %s.obj (in repo under scenes/), .camera rewritten to %dx%d, seed %d" % (args.scene, args.width, args.height, args.seed))
+            if scene_dir is not None else "synthetic lattice scene, %d triangles, generator seed 42 (montecarlopathtracing_amd/synthetic.py)" % scene.info.num_faces,
             "config": {"workload": "%s %dx%d SPP=%d" % (args.scene, args.width, args.height, args.spp), "seed": args.seed,
                        "partition": "32x8-pixel tiles round-robin over ranks, RCCL gather to rank 0",
                        "primary_rays": "traced once per pixel (identical for every sample: the reference has no jitter)"},
@@ -215,7 +228,7 @@ def main():
         if args.save_png and frame is not None:
             img = frame.cpu().numpy()
             M.write_png(args.save_png, M.imshow_rgb8(img))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and scene_dir is not None:
             cb = cpu_baseline(scene_dir, args.scene, args.seed)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu_mrays"] = value / cb["value"]

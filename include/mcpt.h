@@ -89,6 +89,26 @@ int         mcpt_device_count(void);                        /* number of HIP dev
  * relative to <path> first, then the cwd (reference: cwd only). */
 int  mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out);
 void mcpt_scene_free(mcpt_scene*);
+/* The same scene_data from arrays instead of files (generated scenes: the 10 M-triangle stress scene would be ~1 GB of
+ * .obj text).  Faces are given in the order the .obj would list them; Face::norm, Morton keys, per-material face
+ * lists and light tables are derived exactly as read_obj / shade do. */
+typedef struct {
+    int64_t num_faces;
+    const double*  v;               /* [num_faces][9]  v1 v2 v3 */
+    const double*  vn;              /* [num_faces][9]  vn1 vn2 vn3 */
+    const double*  vt;              /* [num_faces][6]  vt1 vt2 vt3, may be NULL (zeros) */
+    const int32_t* material;        /* [num_faces] */
+    int32_t num_materials;
+    const double*  material_rec;    /* [num_materials][8]  Kd xyz, Ks xyz, Ns, Ni */
+    const char* const* material_names;   /* may be NULL */
+    int32_t num_lights;
+    const int32_t* light_material;  /* [num_lights] material that emits (".camera" mtlname lines, in order) */
+    const double*  light_radiance;  /* [num_lights][3] */
+    double eye[3], look_at[3], up[3], fovy;
+    int32_t width, height;
+} mcpt_scene_desc;
+#define MCPT_SCENE_DEFER_BUILD 1    /* leave Morton sort + BVH to the GPU (mcpt_device_create then builds on the device) */
+int  mcpt_scene_create(const mcpt_scene_desc*, int32_t flags, mcpt_scene** out);
 int  mcpt_scene_set_resolution(mcpt_scene*, int32_t width, int32_t height);   /* overrides .camera width/height */
 int  mcpt_scene_get_info(const mcpt_scene*, mcpt_scene_info* out);
 /* faces in .obj order: 27 doubles each = v1 v2 v3 vn1 vn2 vn3 (xyz) vt1 vt2 vt3 (uv) norm; any pointer may be NULL */
@@ -109,6 +129,14 @@ int  mcpt_scene_fast_bvh_stats(const mcpt_scene*, int32_t* n_nodes, int32_t* max
 
 /* ---- device ---- */
 int  mcpt_device_create(const mcpt_scene*, int32_t device_ordinal, mcpt_device** out);
+/* Where sort(scene.f, compare) + BVH::BVH (MTPC/MTPC.cpp:44-45) run: on the host (bvh_build.cpp) or on the GPU
+ * (build_kernels.hip: Morton kernel, stable radix sort of (key, face), leaf records, one union kernel per level).
+ * Both give bit-identical arrays; mcpt_device_get_* read the device's copy back for that comparison. */
+#define MCPT_BUILD_HOST   0
+#define MCPT_BUILD_DEVICE 1
+int  mcpt_device_create_ex(const mcpt_scene*, int32_t device_ordinal, int32_t build_mode, mcpt_device** out);
+int  mcpt_device_get_bvh_nodes(mcpt_device*, double* box6 /* Nr*6, may be NULL */, int32_t* leaf_face /* Nr, may be NULL */);
+int  mcpt_device_get_leaf_order(mcpt_device*, int32_t* leaf_to_face);
 void mcpt_device_free(mcpt_device*);
 /* Which walk the closest-hit queries use.  Both return identical results (tests/test_gpu_parity.py).
  *   MCPT_TRACE_FAST (default): SAH hierarchy over the reference's leaf boxes, conservative culling, distance pruning,

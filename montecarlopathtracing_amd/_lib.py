@@ -47,6 +47,14 @@ class RenderParams(C.Structure):
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("flags", C.c_int32)]
 
 
+class SceneDesc(C.Structure):
+    _fields_ = [("num_faces", C.c_int64), ("v", C.POINTER(C.c_double)), ("vn", C.POINTER(C.c_double)), ("vt", C.POINTER(C.c_double)),
+                ("material", C.POINTER(C.c_int32)), ("num_materials", C.c_int32), ("material_rec", C.POINTER(C.c_double)),
+                ("material_names", C.POINTER(C.c_char_p)), ("num_lights", C.c_int32), ("light_material", C.POINTER(C.c_int32)),
+                ("light_radiance", C.POINTER(C.c_double)), ("eye", C.c_double * 3), ("look_at", C.c_double * 3), ("up", C.c_double * 3),
+                ("fovy", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 class RenderSceneOptions(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("quiet", C.c_int32), ("output_prefix", C.c_char_p)]
@@ -55,10 +63,11 @@ class RenderSceneOptions(C.Structure):
 # every symbol include/mcpt.h declares
 EXPORTS = [
     "mcpt_version", "mcpt_last_error", "mcpt_device_count",
-    "mcpt_scene_load", "mcpt_scene_free", "mcpt_scene_set_resolution", "mcpt_scene_get_info", "mcpt_scene_get_faces",
+    "mcpt_scene_load", "mcpt_scene_create", "mcpt_scene_free", "mcpt_scene_set_resolution", "mcpt_scene_get_info", "mcpt_scene_get_faces",
     "mcpt_scene_get_leaf_order", "mcpt_scene_get_bvh_nodes", "mcpt_scene_find_index", "mcpt_scene_get_material",
     "mcpt_scene_get_light", "mcpt_morton_code", "mcpt_scene_fast_bvh_stats",
-    "mcpt_device_create", "mcpt_device_free", "mcpt_device_set_trace_mode",
+    "mcpt_device_create", "mcpt_device_create_ex", "mcpt_device_get_bvh_nodes", "mcpt_device_get_leaf_order", "mcpt_device_free",
+    "mcpt_device_set_trace_mode",
     "mcpt_trace_closest", "mcpt_trace_closest_device",
     "mcpt_render", "mcpt_render_device", "mcpt_sample_radiance", "mcpt_owned_pixels",
     "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_decode_jpeg",
@@ -88,6 +97,7 @@ def lib():
     L.mcpt_last_error.restype = C.c_char_p
     L.mcpt_device_count.restype = C.c_int
     L.mcpt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(P)]
+    L.mcpt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.POINTER(P)]
     L.mcpt_scene_free.argtypes = [P]
     L.mcpt_scene_free.restype = None
     L.mcpt_scene_set_resolution.argtypes = [P, C.c_int32, C.c_int32]
@@ -102,6 +112,9 @@ def lib():
     L.mcpt_morton_code.argtypes = [C.c_float, C.c_float, C.c_float]
     L.mcpt_scene_fast_bvh_stats.argtypes = [P, I32, I32, I32, I32]
     L.mcpt_device_create.argtypes = [P, C.c_int32, C.POINTER(P)]
+    L.mcpt_device_create_ex.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(P)]
+    L.mcpt_device_get_bvh_nodes.argtypes = [P, D, I32]
+    L.mcpt_device_get_leaf_order.argtypes = [P, I32]
     L.mcpt_device_free.argtypes = [P]
     L.mcpt_device_free.restype = None
     L.mcpt_device_set_trace_mode.argtypes = [P, C.c_int32]

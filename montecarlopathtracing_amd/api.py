@@ -5,11 +5,13 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import McptError, RenderParams, RenderSceneOptions, SceneInfo, Stats, check, lib
+from ._lib import McptError, RenderParams, RenderSceneOptions, SceneDesc, SceneInfo, Stats, check, lib
 
 
 TRACE_FAST, TRACE_REFERENCE = 0, 1
 RENDER_DEFAULT, RENDER_MEGAKERNEL = 0, 2
+BUILD_HOST, BUILD_DEVICE = 0, 1
+SCENE_DEFER_BUILD = 1
 
 
 def _p(a, t):
@@ -28,6 +30,41 @@ class Scene:
         check(lib().mcpt_scene_load(path.encode(), filename.encode(), C.byref(self._h)))
         if width is not None:
             self.set_resolution(width, height)
+
+    @classmethod
+    def from_arrays(cls, v, vn, material, material_rec, light_material, light_radiance, eye, look_at, up, fovy, width, height,
+                    vt=None, material_names=None, defer_build=False):
+        """scene_data from arrays (mcpt_scene_create): faces in .obj order, v/vn [n,9], vt [n,6] or None."""
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 9)
+        vn = np.ascontiguousarray(vn, dtype=np.float64).reshape(-1, 9)
+        n = v.shape[0]
+        material = np.ascontiguousarray(material, dtype=np.int32)
+        material_rec = np.ascontiguousarray(material_rec, dtype=np.float64).reshape(-1, 8)
+        light_material = np.ascontiguousarray(light_material, dtype=np.int32)
+        light_radiance = np.ascontiguousarray(light_radiance, dtype=np.float64).reshape(-1, 3)
+        if vt is not None:
+            vt = np.ascontiguousarray(vt, dtype=np.float64).reshape(-1, 6)
+        d = SceneDesc()
+        d.num_faces = n
+        d.v, d.vn = _p(v, C.c_double), _p(vn, C.c_double)
+        d.vt = _p(vt, C.c_double) if vt is not None else None
+        d.material = _p(material, C.c_int32)
+        d.num_materials = material_rec.shape[0]
+        d.material_rec = _p(material_rec, C.c_double)
+        if material_names is not None:
+            arr = (C.c_char_p * len(material_names))(*[m.encode() for m in material_names])
+            d.material_names = arr
+        d.num_lights = light_material.shape[0]
+        d.light_material = _p(light_material, C.c_int32)
+        d.light_radiance = _p(light_radiance, C.c_double)
+        d.eye = (C.c_double * 3)(*eye)
+        d.look_at = (C.c_double * 3)(*look_at)
+        d.up = (C.c_double * 3)(*up)
+        d.fovy, d.width, d.height = fovy, width, height
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        check(lib().mcpt_scene_create(C.byref(d), SCENE_DEFER_BUILD if defer_build else 0, C.byref(self._h)))
+        return self
 
     def close(self):
         if getattr(self, "_h", None):
@@ -113,10 +150,13 @@ class Scene:
 class Device:
     """One MI355X holding a resident copy of a Scene."""
 
-    def __init__(self, scene, ordinal=0):
+    def __init__(self, scene, ordinal=0, build=None):
         self.scene = scene
         self._h = C.c_void_p()
-        check(lib().mcpt_device_create(scene._h, ordinal, C.byref(self._h)))
+        if build is None:
+            check(lib().mcpt_device_create(scene._h, ordinal, C.byref(self._h)))
+        else:
+            check(lib().mcpt_device_create_ex(scene._h, ordinal, build, C.byref(self._h)))
         i = scene.info
         self.width, self.height = i.width, i.height
 
@@ -126,6 +166,19 @@ class Device:
             self._h = None
 
     __del__ = close
+
+    def bvh_nodes(self):
+        """(box6 [Nr,6], leaf_face [Nr]) read back from HBM."""
+        nr = self.scene.info.bvh.Nr
+        box = np.zeros((nr, 6))
+        leaf = np.zeros(nr, dtype=np.int32)
+        check(lib().mcpt_device_get_bvh_nodes(self._h, _p(box, C.c_double), _p(leaf, C.c_int32)))
+        return box, leaf
+
+    def leaf_order(self):
+        o = np.zeros(self.scene.info.num_faces, dtype=np.int32)
+        check(lib().mcpt_device_get_leaf_order(self._h, _p(o, C.c_int32)))
+        return o
 
     def set_trace_mode(self, mode):
         """TRACE_FAST (default) or TRACE_REFERENCE: which walk answers closest-hit queries (same results)."""

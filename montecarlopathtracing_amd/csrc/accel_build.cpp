@@ -265,19 +265,20 @@ struct Collapser {
 
 }  // namespace
 
-void build_fast_bvh(const Scene& s, FastBvh& out)
+void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out)
 {
     out = FastBvh();
     if (const char* e = std::getenv("MCPT_FAST_LEAF")) kMaxLeafRt = std::max(1, std::min(kFastMaxLeaf, std::atoi(e)));
     if (const char* e = std::getenv("MCPT_FAST_CT")) kCostTri = std::atof(e);
-    const int t = s.bi.t;
     std::vector<Box> prim(t);
-    const int leaf0 = find_index(s.bi, (1 << s.bi.Level) - 1, s.bi.Level);
     double amax = 0;
+    auto mx3 = [](double a, double b, double c) { if (a >= b && a >= c) return a; if (b >= a && b >= c) return b; return c; };   // dmax
+    auto mn3 = [](double a, double b, double c) { if (a <= b && a <= c) return a; if (b <= a && b <= c) return b; return c; };   // dmin
     for (int k = 0; k < t; k++) {
-        const NodeBox& nb = s.nodes[leaf0 + k];          // the reference's own leaf box of leaf k
-        prim[k].lo[0] = nb.min_x; prim[k].lo[1] = nb.min_y; prim[k].lo[2] = nb.min_z;
-        prim[k].hi[0] = nb.max_x; prim[k].hi[1] = nb.max_y; prim[k].hi[2] = nb.max_z;
+        const FaceRec& f = faces[order[k]];            // the reference's own leaf box of leaf k (BVH.cpp:87-97)
+        prim[k].lo[0] = mn3(f.v[0].x, f.v[1].x, f.v[2].x); prim[k].hi[0] = mx3(f.v[0].x, f.v[1].x, f.v[2].x);
+        prim[k].lo[1] = mn3(f.v[0].y, f.v[1].y, f.v[2].y); prim[k].hi[1] = mx3(f.v[0].y, f.v[1].y, f.v[2].y);
+        prim[k].lo[2] = mn3(f.v[0].z, f.v[1].z, f.v[2].z); prim[k].hi[2] = mx3(f.v[0].z, f.v[1].z, f.v[2].z);
         for (int a = 0; a < 3; a++) {
             if (std::isfinite(prim[k].lo[a])) amax = std::max(amax, std::fabs(prim[k].lo[a]));
             if (std::isfinite(prim[k].hi[a])) amax = std::max(amax, std::fabs(prim[k].hi[a]));

@@ -22,6 +22,7 @@ struct FastBvh {
     int max_depth = 0;
 };
 
-void build_fast_bvh(const Scene& s, FastBvh& out);
+// order[k] = .obj face held by reference leaf k
+void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out);
 
 }  // namespace mcpt

@@ -1,0 +1,24 @@
+// Device build of Morton keys, Morton ordering, leaf records and the implicit tree's boxes (build_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/mcpt.h"
+#include "device_scene.hpp"
+
+namespace mcpt {
+
+struct BuildInputs {            // faces in .obj order, device pointers
+    const double* v9;           // [t][9]  v1 v2 v3
+    const double* vn9;          // [t][9]
+    const double* vt6;          // [t][6]
+    const double* nrm3;         // [t][3]  Face::norm
+    const int32_t* material;    // [t]
+    int t;
+};
+
+// fills nodes[Nr] (compact level order), tris[t], shade[t] (leaf order) and d_order[t] (leaf -> .obj face)
+hipError_t device_build_reference(const BuildInputs& in, const mcpt_bvh_info& bi, DNode* nodes, DTri* tris, DTriShade* shade,
+                                  int32_t* d_order, hipStream_t st);
+hipError_t device_gather_tris(const DTri* tris, const int32_t* d_slots, int n, DTri* out, hipStream_t st);
+
+}  // namespace mcpt

@@ -63,6 +63,21 @@ bool has_right_child(const mcpt_bvh_info& b, int node, int l)
     return 2L * node + 2 < first_virtual;
 }
 
+// t, Lc, Lv, Nc, Nv, Nr, Level of BVH.cpp:46-52 for t faces
+mcpt_bvh_info bvh_shape(int t)
+{
+    mcpt_bvh_info b{};
+    b.t = t;
+    b.Lc = 1;
+    b.Level = 0;
+    while (b.Lc < t) { b.Lc <<= 1; b.Level++; }    // Lc = 2^ceil(log2 t); Level = floor(log2(2 Lc - 1)) = log2 Lc
+    b.Lv = b.Lc - t;
+    b.Nc = 2 * b.Lc - 1;
+    b.Nv = 2 * b.Lv - popcount32(b.Lv);
+    b.Nr = 2 * t - 1 + popcount32(b.Lv);
+    return b;
+}
+
 int build_accel(Scene& s, std::string& err)
 {
     const int t = int(s.faces.size());
@@ -73,15 +88,8 @@ int build_accel(Scene& s, std::string& err)
     std::stable_sort(s.order.begin(), s.order.end(),
                      [&](int a, int b) { return s.faces[a].morton < s.faces[b].morton; });
 
-    mcpt_bvh_info& b = s.bi;                       // BVH.cpp:46-52
-    b.t = t;
-    b.Lc = 1;
-    b.Level = 0;
-    while (b.Lc < t) { b.Lc <<= 1; b.Level++; }    // Lc = 2^ceil(log2 t); Level = floor(log2(2 Lc - 1)) = log2 Lc
-    b.Lv = b.Lc - t;
-    b.Nc = 2 * b.Lc - 1;
-    b.Nv = 2 * b.Lv - popcount32(b.Lv);
-    b.Nr = 2 * t - 1 + popcount32(b.Lv);
+    s.bi = bvh_shape(t);
+    mcpt_bvh_info& b = s.bi;
 
     s.nodes.assign(b.Nr, NodeBox{});
     s.node_level.assign(b.Nr, 0);
@@ -119,6 +127,7 @@ int build_accel(Scene& s, std::string& err)
             }
         }
     }
+    s.accel_built = true;
     return MCPT_OK;
 }
 

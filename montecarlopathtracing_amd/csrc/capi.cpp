@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "accel_build.hpp"
+#include "build_kernels.hpp"
 #include "jpeg_decoder.hpp"
 #include "kernels.hpp"
 #include "scene.hpp"
@@ -68,6 +69,8 @@ struct mcpt_device {
     DLight* lights = nullptr; DLightTri* light_tris = nullptr; double* light_cdf = nullptr; uint8_t* texels = nullptr;
     FastNode* fast_nodes = nullptr; DTri* fast_tris = nullptr; CwNode* cw_nodes = nullptr;
     int trace_mode = MCPT_TRACE_FAST;
+    int32_t* d_order = nullptr;            // leaf -> .obj face (device build keeps it for read-back)
+    mcpt_bvh_info bi{};
     // frame state
     int width = 0, height = 0;
     double* dirs = nullptr;                // W*H*3 primary directions
@@ -117,6 +120,61 @@ int mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out)
 }
 void mcpt_scene_free(mcpt_scene* s) { delete s; }
 
+int mcpt_scene_create(const mcpt_scene_desc* dsc, int32_t flags, mcpt_scene** out)
+{
+    if (!dsc || !out) return fail(MCPT_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (dsc->num_faces <= 0 || dsc->num_faces > 0x3fffffff || !dsc->v || !dsc->vn || !dsc->material || dsc->num_materials <= 0 ||
+        !dsc->material_rec || dsc->num_lights < 0 || (dsc->num_lights && (!dsc->light_material || !dsc->light_radiance)))
+        return fail(MCPT_ERR_ARG, "incomplete scene description");
+    std::unique_ptr<mcpt_scene> h(new mcpt_scene);
+    Scene& s = h->s;
+    s.materials.resize(size_t(dsc->num_materials));
+    for (int m = 0; m < dsc->num_materials; m++) {
+        MaterialRec& r = s.materials[m];
+        const double* q = dsc->material_rec + size_t(m) * 8;
+        r.name = (dsc->material_names && dsc->material_names[m]) ? dsc->material_names[m] : ("material" + std::to_string(m));
+        r.kd = Vec3{q[0], q[1], q[2]}; r.ks = Vec3{q[3], q[4], q[5]}; r.Ns = q[6]; r.Ni = q[7];
+    }
+    const int64_t t = dsc->num_faces;
+    s.faces.resize(size_t(t));
+    for (int64_t i = 0; i < t; i++) {
+        FaceRec& f = s.faces[size_t(i)];
+        const int m = dsc->material[i];
+        if (m < 0 || m >= dsc->num_materials) return fail(MCPT_ERR_PARSE, "face material index out of range");
+        for (int c = 0; c < 3; c++) {
+            f.v[c] = Vec3{dsc->v[i * 9 + c * 3], dsc->v[i * 9 + c * 3 + 1], dsc->v[i * 9 + c * 3 + 2]};
+            f.vn[c] = Vec3{dsc->vn[i * 9 + c * 3], dsc->vn[i * 9 + c * 3 + 1], dsc->vn[i * 9 + c * 3 + 2]};
+            f.vt[c][0] = dsc->vt ? dsc->vt[i * 6 + c * 2] : 0.0; f.vt[c][1] = dsc->vt ? dsc->vt[i * 6 + c * 2 + 1] : 0.0;
+        }
+        f.material = m;
+        f.nrm = normalized(cross(f.v[0] - f.v[1], f.v[2] - f.v[0]));              // Face::calNorm
+        const Vec3 center = (f.v[0] + f.v[1] + f.v[2]) / 3;
+        f.morton = morton_code(float(center.x), float(center.y), float(center.z));
+        s.materials[m].faces.push_back(int32_t(i));
+    }
+    s.lights.resize(size_t(dsc->num_lights));
+    for (int l = 0; l < dsc->num_lights; l++) {
+        LightRec& r = s.lights[l];
+        r.material = dsc->light_material[l];
+        if (r.material < 0 || r.material >= dsc->num_materials) return fail(MCPT_ERR_PARSE, "light material index out of range");
+        r.name = s.materials[r.material].name;
+        r.radiance = Vec3{dsc->light_radiance[l * 3], dsc->light_radiance[l * 3 + 1], dsc->light_radiance[l * 3 + 2]};
+    }
+    s.eye = Vec3{dsc->eye[0], dsc->eye[1], dsc->eye[2]}; s.look_at = Vec3{dsc->look_at[0], dsc->look_at[1], dsc->look_at[2]};
+    s.up = Vec3{dsc->up[0], dsc->up[1], dsc->up[2]}; s.fovy = dsc->fovy; s.width = dsc->width; s.height = dsc->height;
+    std::string err;
+    int rc = finish_scene(s, "scene description", err);
+    if (rc) return fail(rc, err);
+    s.bi = bvh_shape(int(t));
+    if (!(flags & MCPT_SCENE_DEFER_BUILD)) {
+        rc = build_accel(s, err);
+        if (rc) return fail(rc, err);
+    }
+    *out = h.release();
+    return MCPT_OK;
+}
+
 int mcpt_scene_set_resolution(mcpt_scene* s, int32_t w, int32_t h)
 {
     if (!s || w <= 0 || h <= 0) return fail(MCPT_ERR_ARG, "bad resolution");
@@ -159,6 +217,7 @@ int mcpt_scene_get_faces(const mcpt_scene* h, double* g, int32_t* material, uint
 int mcpt_scene_get_leaf_order(const mcpt_scene* h, int32_t* o)
 {
     if (!h || !o) return fail(MCPT_ERR_ARG, "null argument");
+    if (!h->s.accel_built) return fail(MCPT_ERR_ARG, "scene has no host build (MCPT_SCENE_DEFER_BUILD): read the device's copy");
     std::copy(h->s.order.begin(), h->s.order.end(), o);
     return MCPT_OK;
 }
@@ -167,6 +226,7 @@ int mcpt_scene_get_bvh_nodes(const mcpt_scene* h, double* box6, int32_t* level, 
 {
     if (!h) return fail(MCPT_ERR_ARG, "null scene");
     const Scene& s = h->s;
+    if (!s.accel_built) return fail(MCPT_ERR_ARG, "scene has no host build (MCPT_SCENE_DEFER_BUILD): read the device's copy");
     for (int i = 0; i < s.bi.Nr; i++) {
         const NodeBox& b = s.nodes[i];
         if (box6) { double* o = box6 + size_t(i) * 6; o[0] = b.max_x; o[1] = b.max_y; o[2] = b.max_z; o[3] = b.min_x; o[4] = b.min_y; o[5] = b.min_z; }
@@ -205,7 +265,8 @@ int mcpt_scene_fast_bvh_stats(const mcpt_scene* h, int32_t* n_nodes, int32_t* ma
 {
     if (!h) return fail(MCPT_ERR_ARG, "null scene");
     FastBvh fb;
-    build_fast_bvh(h->s, fb);
+    if (!h->s.accel_built) return fail(MCPT_ERR_ARG, "scene was created without a host build");
+    build_fast_bvh(h->s.faces, h->s.order.data(), h->s.bi.t, fb);
     if (n_nodes) *n_nodes = int32_t(fb.nodes.size());
     if (max_depth) *max_depth = fb.max_depth;
     if (leaf_order) std::copy(fb.leaf_tris.begin(), fb.leaf_tris.end(), leaf_order);
@@ -320,7 +381,7 @@ void mcpt_device_free(mcpt_device* d)
 {
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
-    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes,
+    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes, d->d_order,
                     d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->wf_counts, d->queue, d->slow_list};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -330,42 +391,89 @@ void mcpt_device_free(mcpt_device* d)
 
 int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
 {
+    return mcpt_device_create_ex(h, ordinal, (h && !h->s.accel_built) ? MCPT_BUILD_DEVICE : MCPT_BUILD_HOST, out);
+}
+
+int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mode, mcpt_device** out)
+{
     if (!h || !out) return fail(MCPT_ERR_ARG, "null argument");
     *out = nullptr;
+    if (build_mode != MCPT_BUILD_HOST && build_mode != MCPT_BUILD_DEVICE) return fail(MCPT_ERR_ARG, "bad build mode");
+    const Scene& s = h->s;
+    if (build_mode == MCPT_BUILD_HOST && !s.accel_built) return fail(MCPT_ERR_ARG, "scene has no host build; use MCPT_BUILD_DEVICE");
     int ndev = mcpt_device_count();
     if (ndev <= 0) return fail(MCPT_ERR_NO_DEVICE, "no HIP device available (libmcpt has no CPU fallback)");
     if (ordinal < 0 || ordinal >= ndev) return fail(MCPT_ERR_NO_DEVICE, "device ordinal out of range");
     HIP_TRY(hipSetDevice(ordinal));
-    const Scene& s = h->s;
     std::unique_ptr<mcpt_device, void (*)(mcpt_device*)> d(new mcpt_device, mcpt_device_free);
     d->ordinal = ordinal;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
 
-    const int t = s.bi.t;
-    std::vector<DNode> nodes(s.bi.Nr);
-    for (int i = 0; i < s.bi.Nr; i++) {
-        const NodeBox& b = s.nodes[i];
-        DNode n{};
-        n.mn[0] = b.min_x; n.mn[1] = b.min_y; n.mn[2] = b.min_z; n.mx[0] = b.max_x; n.mx[1] = b.max_y; n.mx[2] = b.max_z;
-        nodes[i] = n;
+    const int t = int(s.faces.size());
+    const mcpt_bvh_info bi = bvh_shape(t);
+    d->bi = bi;
+    int rc;
+    std::vector<int32_t> order;                     // leaf -> .obj face
+    if (build_mode == MCPT_BUILD_HOST) {
+        std::vector<DNode> nodes(bi.Nr);
+        for (int i = 0; i < bi.Nr; i++) {
+            const NodeBox& b = s.nodes[i];
+            DNode n{};
+            n.mn[0] = b.min_x; n.mn[1] = b.min_y; n.mn[2] = b.min_z; n.mx[0] = b.max_x; n.mx[1] = b.max_y; n.mx[2] = b.max_z;
+            nodes[i] = n;
+        }
+        std::vector<DTri> tris(t);
+        std::vector<DTriShade> shade(t);
+        for (int k = 0; k < t; k++) {
+            const FaceRec& f = s.faces[s.order[k]];
+            DTri q{};
+            DTriShade a{};
+            const Vec3* vs[3] = {&f.v[0], &f.v[1], &f.v[2]};
+            double* dst[3] = {q.v1, q.v2, q.v3};
+            for (int c = 0; c < 3; c++) { dst[c][0] = vs[c]->x; dst[c][1] = vs[c]->y; dst[c][2] = vs[c]->z; }
+            q.n[0] = f.nrm.x; q.n[1] = f.nrm.y; q.n[2] = f.nrm.z;
+            q.material = f.material; q.face = s.order[k]; q.leaf = k;
+            double* nd[3] = {a.vn1, a.vn2, a.vn3};
+            for (int c = 0; c < 3; c++) { nd[c][0] = f.vn[c].x; nd[c][1] = f.vn[c].y; nd[c][2] = f.vn[c].z; }
+            a.vt1[0] = f.vt[0][0]; a.vt1[1] = f.vt[0][1]; a.vt2[0] = f.vt[1][0]; a.vt2[1] = f.vt[1][1]; a.vt3[0] = f.vt[2][0]; a.vt3[1] = f.vt[2][1];
+            tris[k] = q; shade[k] = a;
+        }
+        order = s.order;
+        if ((rc = upload(nodes, &d->nodes)) || (rc = upload(tris, &d->tris)) || (rc = upload(shade, &d->shade)) || (rc = upload(order, &d->d_order)))
+            return rc;
+    } else {
+        // faces in .obj order -> HBM, then Morton keys, stable sort, leaf records and the level-by-level union on the GPU
+        std::vector<double> v9(size_t(t) * 9), vn9(size_t(t) * 9), vt6(size_t(t) * 6), nrm3(size_t(t) * 3);
+        std::vector<int32_t> mat(t);
+        for (int i = 0; i < t; i++) {
+            const FaceRec& f = s.faces[i];
+            for (int c = 0; c < 3; c++) {
+                v9[size_t(i) * 9 + c * 3] = f.v[c].x; v9[size_t(i) * 9 + c * 3 + 1] = f.v[c].y; v9[size_t(i) * 9 + c * 3 + 2] = f.v[c].z;
+                vn9[size_t(i) * 9 + c * 3] = f.vn[c].x; vn9[size_t(i) * 9 + c * 3 + 1] = f.vn[c].y; vn9[size_t(i) * 9 + c * 3 + 2] = f.vn[c].z;
+                vt6[size_t(i) * 6 + c * 2] = f.vt[c][0]; vt6[size_t(i) * 6 + c * 2 + 1] = f.vt[c][1];
+            }
+            nrm3[size_t(i) * 3] = f.nrm.x; nrm3[size_t(i) * 3 + 1] = f.nrm.y; nrm3[size_t(i) * 3 + 2] = f.nrm.z;
+            mat[i] = f.material;
+        }
+        double *d_v9 = nullptr, *d_vn9 = nullptr, *d_vt6 = nullptr, *d_nrm3 = nullptr;
+        int32_t* d_mat = nullptr;
+        auto drop = [&]() { (void)hipFree(d_v9); (void)hipFree(d_vn9); (void)hipFree(d_vt6); (void)hipFree(d_nrm3); (void)hipFree(d_mat); };
+        if ((rc = upload(v9, &d_v9)) || (rc = upload(vn9, &d_vn9)) || (rc = upload(vt6, &d_vt6)) || (rc = upload(nrm3, &d_nrm3)) || (rc = upload(mat, &d_mat))) { drop(); return rc; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d->nodes), size_t(bi.Nr) * sizeof(DNode));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->tris), size_t(t) * sizeof(DTri));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->shade), size_t(t) * sizeof(DTriShade));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->d_order), size_t(t) * sizeof(int32_t));
+        if (e == hipSuccess) {
+            BuildInputs in{d_v9, d_vn9, d_vt6, d_nrm3, d_mat, t};
+            e = device_build_reference(in, bi, d->nodes, d->tris, d->shade, d->d_order, d->stream);
+        }
+        order.resize(t);
+        if (e == hipSuccess) e = hipMemcpy(order.data(), d->d_order, size_t(t) * sizeof(int32_t), hipMemcpyDeviceToHost);
+        drop();
+        if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("device build: ") + hipGetErrorString(e));
     }
-    std::vector<DTri> tris(t);
-    std::vector<DTriShade> shade(t);
-    for (int k = 0; k < t; k++) {
-        const FaceRec& f = s.faces[s.order[k]];
-        DTri q{};
-        DTriShade a{};
-        const Vec3* vs[3] = {&f.v[0], &f.v[1], &f.v[2]};
-        double* dst[3] = {q.v1, q.v2, q.v3};
-        for (int c = 0; c < 3; c++) { dst[c][0] = vs[c]->x; dst[c][1] = vs[c]->y; dst[c][2] = vs[c]->z; }
-        q.n[0] = f.nrm.x; q.n[1] = f.nrm.y; q.n[2] = f.nrm.z;
-        q.material = f.material; q.face = s.order[k]; q.leaf = k;
-        double* nd[3] = {a.vn1, a.vn2, a.vn3};
-        for (int c = 0; c < 3; c++) { nd[c][0] = f.vn[c].x; nd[c][1] = f.vn[c].y; nd[c][2] = f.vn[c].z; }
-        a.vt1[0] = f.vt[0][0]; a.vt1[1] = f.vt[0][1]; a.vt2[0] = f.vt[1][0]; a.vt2[1] = f.vt[1][1]; a.vt3[0] = f.vt[2][0]; a.vt3[1] = f.vt[2][1];
-        tris[k] = q; shade[k] = a;
-    }
+
     std::vector<uint8_t> texels;
     std::vector<DMaterial> mats(s.materials.size());
     for (size_t i = 0; i < s.materials.size(); i++) {
@@ -401,16 +509,13 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
         }
         lights[i] = dl;
     }
-    int rc;
-    if ((rc = upload(nodes, &d->nodes)) || (rc = upload(tris, &d->tris)) || (rc = upload(shade, &d->shade)) ||
-        (rc = upload(mats, &d->materials)) || (rc = upload(lights, &d->lights)) || (rc = upload(ltris, &d->light_tris)) ||
+    if ((rc = upload(mats, &d->materials)) || (rc = upload(lights, &d->lights)) || (rc = upload(ltris, &d->light_tris)) ||
         (rc = upload(lcdf, &d->light_cdf)) || (rc = upload(texels, &d->texels)))
         return rc;
-    // result-identical fast structure (accel_build.cpp)
+
+    // result-identical fast structure (accel_build.cpp): built on the host from the leaf order, permuted triangle copy gathered on the GPU
     FastBvh fb;
-    build_fast_bvh(s, fb);
-    std::vector<DTri> ftris(fb.leaf_tris.size());
-    for (size_t i = 0; i < fb.leaf_tris.size(); i++) ftris[i] = tris[fb.leaf_tris[i]];
+    build_fast_bvh(s.faces, order.data(), t, fb);
     bool coords_ok = true;                       // every coordinate zero or within [1e-150, 1e150]
     for (const FaceRec& f : s.faces)
         for (int c = 0; c < 3; c++)
@@ -418,7 +523,15 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
                 const double a = std::fabs(v);
                 if (!(a == 0.0 || (a >= 1e-150 && a <= 1e150))) coords_ok = false;
             }
-    if ((rc = upload(fb.nodes, &d->fast_nodes)) || (rc = upload(ftris, &d->fast_tris)) || (rc = upload(fb.cw, &d->cw_nodes))) return rc;
+    {
+        int32_t* d_slots = nullptr;
+        if ((rc = upload(fb.cw, &d->cw_nodes)) || (rc = upload(fb.leaf_tris, &d_slots))) { (void)hipFree(d_slots); return rc; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d->fast_tris), std::max<size_t>(fb.leaf_tris.size(), 1) * sizeof(DTri));
+        if (e == hipSuccess) e = device_gather_tris(d->tris, d_slots, int(fb.leaf_tris.size()), d->fast_tris, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        (void)hipFree(d_slots);
+        if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("fast triangle gather: ") + hipGetErrorString(e));
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->ctr), sizeof(DCounters)));
     HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->wf_counts), sizeof(WfCounts)));
@@ -433,10 +546,10 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
     DScene& S = d->ds;
     S.nodes = d->nodes; S.tris = d->tris; S.shade = d->shade; S.materials = d->materials; S.lights = d->lights;
     S.light_tris = d->light_tris; S.light_cdf = d->light_cdf; S.texels = d->texels;
-    S.t = t; S.Lv = s.bi.Lv; S.Level = s.bi.Level; S.Nr = s.bi.Nr;
+    S.t = t; S.Lv = bi.Lv; S.Level = bi.Level; S.Nr = bi.Nr;
     S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
     S.area0 = s.area0;
-    S.fast.cw = d->cw_nodes; S.fast.nodes = d->fast_nodes; S.fast.tris = d->fast_tris; S.fast.absmax = fb.scene_absmax;
+    S.fast.cw = d->cw_nodes; S.fast.nodes = nullptr; S.fast.tris = d->fast_tris; S.fast.absmax = fb.scene_absmax;
     S.fast.enabled = (coords_ok && fb.max_depth < kFastMaxDepth && fb.cw_stack_need < kFastMaxDepth && fb.scene_absmax >= 1e-15 &&
                       fb.scene_absmax <= 1e15) ? 1 : 0;
     const CameraFrame cf = camera_frame(s);
@@ -448,6 +561,37 @@ int mcpt_device_create(const mcpt_scene* h, int32_t ordinal, mcpt_device** out)
     d->width = s.width; d->height = s.height;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->dirs), size_t(s.width) * s.height * 3 * sizeof(double)));
     *out = d.release();
+    return MCPT_OK;
+}
+
+// what the device holds, read back (parity of the device build against the host build)
+int mcpt_device_get_bvh_nodes(mcpt_device* d, double* box6, int32_t* leaf_face)
+{
+    if (!d) return fail(MCPT_ERR_ARG, "null device");
+    HIP_TRY(hipSetDevice(d->ordinal));
+    const mcpt_bvh_info& bi = d->bi;
+    if (box6) {
+        std::vector<DNode> nodes(bi.Nr);
+        HIP_TRY(hipMemcpy(nodes.data(), d->nodes, size_t(bi.Nr) * sizeof(DNode), hipMemcpyDeviceToHost));
+        for (int i = 0; i < bi.Nr; i++) {
+            double* o = box6 + size_t(i) * 6;
+            o[0] = nodes[i].mx[0]; o[1] = nodes[i].mx[1]; o[2] = nodes[i].mx[2]; o[3] = nodes[i].mn[0]; o[4] = nodes[i].mn[1]; o[5] = nodes[i].mn[2];
+        }
+    }
+    if (leaf_face) {
+        std::vector<int32_t> order(bi.t);
+        HIP_TRY(hipMemcpy(order.data(), d->d_order, size_t(bi.t) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        const int leaf0 = find_index(bi, (1 << bi.Level) - 1, bi.Level);
+        for (int i = 0; i < bi.Nr; i++) leaf_face[i] = (i >= leaf0 && i < leaf0 + bi.t) ? order[i - leaf0] : -1;
+    }
+    return MCPT_OK;
+}
+
+int mcpt_device_get_leaf_order(mcpt_device* d, int32_t* leaf_to_face)
+{
+    if (!d || !leaf_to_face) return fail(MCPT_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(d->ordinal));
+    HIP_TRY(hipMemcpy(leaf_to_face, d->d_order, size_t(d->bi.t) * sizeof(int32_t), hipMemcpyDeviceToHost));
     return MCPT_OK;
 }
 

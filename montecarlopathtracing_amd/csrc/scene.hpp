@@ -69,15 +69,19 @@ struct Scene {
     std::vector<NodeBox> nodes;           // Nr real nodes, compact level order
     std::vector<int32_t> node_level, node_leaf;
     double area0 = 0;                     // total area of lights[0] (Q1)
+    bool accel_built = false;             // false: Morton sort + BVH are left to the device (mcpt_device_create_ex)
 };
 
 // scene_loader.cpp
 int load_scene_files(const std::string& path, const std::string& filename, Scene& out, std::string& err);
+int finish_scene(Scene& s, const std::string& what, std::string& err);
+int find_material(const Scene& s, const std::string& name);
 // bvh_build.cpp
 uint32_t morton_code(float x, float y, float z);
 int find_index(const mcpt_bvh_info& b, int i, int l);
 bool has_right_child(const mcpt_bvh_info& b, int node, int l);
 int build_accel(Scene& s, std::string& err);
+mcpt_bvh_info bvh_shape(int t);
 double face_area(const FaceRec& f);
 // png_writer.cpp
 int64_t png_encode(const uint8_t* rgb8, int w, int h, uint8_t* out, int64_t cap);

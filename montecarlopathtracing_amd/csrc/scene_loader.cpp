@@ -17,6 +17,14 @@
 #include "scene.hpp"
 
 namespace mcpt {
+
+int find_material(const Scene& s, const std::string& name)
+{
+    for (size_t i = 0; i < s.materials.size(); i++)
+        if (s.materials[i].name == name) return int(i);
+    return -1;
+}
+
 namespace {
 
 bool next_line(std::ifstream& in, std::string& line)
@@ -93,12 +101,6 @@ bool load_texture(const std::string& dir, const std::string& name, MaterialRec& 
     return false;
 }
 
-int find_material(const Scene& s, const std::string& name)
-{
-    for (size_t i = 0; i < s.materials.size(); i++)
-        if (s.materials[i].name == name) return int(i);
-    return -1;
-}
 
 // scene_data::read_mtl, sceneManagement.cpp:17-74
 int read_mtl(const std::string& file, const std::string& dir, Scene& s, std::string& err)
@@ -253,16 +255,23 @@ int load_scene_files(const std::string& path, const std::string& filename, Scene
     if (rc) return rc;
     rc = read_camera(base + ".camera", s, err);
     if (rc) return rc;
-    if (s.faces.empty()) { err = base + ".obj has no faces"; return MCPT_ERR_PARSE; }
-    if (s.width <= 0 || s.height <= 0) { err = base + ".camera has no width/height"; return MCPT_ERR_PARSE; }
+    return finish_scene(s, base, err);
+}
+
+// what read_scene leaves behind once the three files are in: sanity checks, lights -> materials, light area tables
+int finish_scene(Scene& s, const std::string& what, std::string& err)
+{
+    if (s.faces.empty()) { err = what + " has no faces"; return MCPT_ERR_PARSE; }
+    if (s.width <= 0 || s.height <= 0) { err = what + " has no width/height"; return MCPT_ERR_PARSE; }
     for (size_t i = 0; i < s.lights.size(); i++) {
         LightRec& l = s.lights[i];
-        l.material = find_material(s, l.name);
-        if (l.material < 0) { err = "light '" + l.name + "' names no material"; return MCPT_ERR_PARSE; }
+        if (l.material < 0) l.material = find_material(s, l.name);
+        if (l.material < 0 || l.material >= int(s.materials.size())) { err = "light '" + l.name + "' names no material"; return MCPT_ERR_PARSE; }
         s.materials[l.material].light = int32_t(i);      // light_map[name]: the last entry wins
         const MaterialRec& m = s.materials[l.material];
         double total = 0;
         l.cdf.resize(m.faces.size());
+        l.cdf_sorted = true;
         for (size_t j = 0; j < m.faces.size(); j++) {
             total += face_area(s.faces[m.faces[j]]);
             l.cdf[j] = total;

@@ -248,3 +248,24 @@ def test_scene_loads_from_the_jpeg_alone(mcpt, oracle, tmp_path):
         os.chdir(cwd)
     name, rec, fl = sc.material(6)
     assert name == "Table" and list(fl[:3]) == [1, 612, 408]
+
+
+def test_scene_from_arrays_equals_scene_from_files(mcpt, oracle, tmp_path):
+    """mcpt_scene_create (generated scenes) against the file loader and the oracle on the same synthetic scene."""
+    from montecarlopathtracing_amd import synthetic
+    g = synthetic.generate(3000, width=48, height=27)
+    sc = mcpt.Scene.from_arrays(g["v"], g["vn"], g["material"], g["material_rec"], g["light_material"], g["light_radiance"], g["eye"],
+                                g["look_at"], g["up"], g["fovy"], g["width"], g["height"], material_names=g["material_names"])
+    synthetic.write_obj(g, str(tmp_path), "syn")
+    sf = mcpt.Scene(str(tmp_path) + os.sep, "syn")
+    osc = oracle.OracleScene(str(tmp_path / "syn"), texture_dir=str(tmp_path))
+    for a, b in zip(sc.faces(), sf.faces()):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.array_equal(sc.leaf_order(), sf.leaf_order()) and np.array_equal(sc.leaf_order(), osc.leaf_order())
+    assert np.array_equal(_bits(sc.bvh_nodes()[0]), _bits(osc.bvh_nodes()[0]))
+    assert sc.info.num_lights == 4 and sc.light(2)[0] == "Light3" and sc.light(2)[3] == osc.light(2)[3]
+    deferred = mcpt.Scene.from_arrays(g["v"], g["vn"], g["material"], g["material_rec"], g["light_material"], g["light_radiance"],
+                                      g["eye"], g["look_at"], g["up"], g["fovy"], g["width"], g["height"], defer_build=True)
+    assert deferred.info.bvh.Nr == sc.info.bvh.Nr
+    with pytest.raises(mcpt.McptError):
+        deferred.leaf_order()
