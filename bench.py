@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-png", default=None)
     ap.add_argument("--tris", type=int, default=10_000_000, help="--scene synthetic: number of lattice triangles")
+    ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: render only rank 0's tiles of an N-rank partition on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -161,6 +162,16 @@ def main():
         scene = M.Scene(scene_dir, args.scene)
         dev = M.Device(scene, local_rank)
     rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev)
+    if args.sim_world > 1:          # one rank's share of an N-way partition, no communication
+        class _Sim:
+            def __init__(self):
+                import torch as _t
+                self.frame = _t.zeros((scene.info.height * scene.info.width, 3), dtype=_t.float64, device=tdev)
+            def render(self, spp, seed=0, stats=None, flags=0):
+                dev.render_device(self.frame.data_ptr(), spp, seed, 0, args.sim_world, 0, 0, flags, stats,
+                                  torch.cuda.current_stream(tdev).cuda_stream)
+                return self.frame
+        rr = _Sim()
 
     def sync():
         if world > 1:

@@ -69,8 +69,9 @@ typedef struct {
 typedef struct {
     int32_t  spp;            /* N_ray_per_pixel */
     uint64_t seed;           /* RNG seam key (D1) */
-    /* pixel ownership: the frame is cut into tile_w x tile_h tiles numbered row-major; this call renders
-     * tiles with (tile % world) == rank.  world<=1 renders everything.  tile_w/h <= 0 -> 32 x 8. */
+    /* pixel ownership: the frame is cut into tile_w x tile_h tiles; tile (tx, ty) belongs to rank
+     * (tx + shift*ty) mod world, shift = first integer >= world/2 coprime with world (round-robin along a row, every
+     * row starting on another rank).  world<=1 renders everything.  tile_w/h <= 0 -> 32 x 8. */
     int32_t  rank, world, tile_w, tile_h;
     int32_t  flags;          /* MCPT_RENDER_* */
 } mcpt_render_params;

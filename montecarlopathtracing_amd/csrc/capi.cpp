@@ -86,7 +86,8 @@ struct mcpt_device {
     size_t wf_budget_bytes = size_t(40) << 30;      // path state + rays (MCPT_WORKSPACE_GB overrides)
     void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
     int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
-    WfCounts* wf_counts = nullptr;
+    WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // start/stop pairs around trace launches
     TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
     long long* slow_list = nullptr;
     unsigned int slow_cap = 1u << 20;
@@ -351,15 +352,26 @@ static void tile_shape(const mcpt_render_params* p, int& tw, int& th, int& rank,
     rank = (p && world > 1) ? p->rank : 0;
 }
 
+// Tile (tx, ty) belongs to rank (tx + shift*ty) mod world, shift = the first integer >= world/2 that is coprime with
+// world: consecutive tiles of a row go round-robin over the ranks and every tile row starts on a different rank, so no
+// rank ends up with a fixed set of image columns (a plain "tile index mod world" does when the row length is a multiple
+// of world -- 1280/32 = 40 tiles per row with 8 ranks -- and the empty sides of a frame then unbalance the ranks).
+static int tile_shift(int world)
+{
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    for (int s = std::max(1, world / 2); s < world; s++) if (gcd(s, world) == 1) return s;
+    return 1;
+}
+
 static void owned_pixel_list(int W, int H, int tw, int th, int rank, int world, std::vector<int32_t>& out)
 {
     out.clear();
-    const int tiles_x = (W + tw - 1) / tw;
+    const int shift = tile_shift(world);
     for (int y = 0; y < H; y++) {
         const int ty = y / th;
         for (int x = 0; x < W; x++) {
-            const int tile = ty * tiles_x + x / tw;
-            if (tile % world == rank) out.push_back(y * W + x);
+            const int tx = x / tw;
+            if ((tx + shift * ty) % world == rank) out.push_back(y * W + x);
         }
     }
 }
@@ -385,6 +397,7 @@ void mcpt_device_free(mcpt_device* d)
                     d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->wf_counts, d->queue, d->slow_list};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& pr : d->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -534,7 +547,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->ctr), sizeof(DCounters)));
     HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->wf_counts), sizeof(WfCounts)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->wf_counts), sizeof(WfCounts) * MCPT_WF_COUNT_SLOTS));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->queue), sizeof(TraceQueue)));
     if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->slow_list), size_t(d->slow_cap) * sizeof(long long)));
@@ -778,51 +791,65 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
     if (!wf_carve(d->wf_ws, d->wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
     a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = d->hit_slots; a.hits = d->hits;
     a.dirs = d->dirs; a.rad = d->rad; a.counts = d->wf_counts; a.ctr = d->ctr; a.tris = d->tris;
-    bool pending = false;            // a timed trace launch whose events have not been read yet
-    auto read_pending = [&]() -> int {
-        if (pending) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, d->ev[2], d->ev[3]));
-            ms_trace += ms; pending = false;
+    // Iterations are enqueued without waiting for their counts: every kernel reads its input count from the device slot the
+    // previous one wrote.  The host looks at a count only every few iterations (to stop, and to size the next grids).
+    size_t ev_used = 0;
+    auto next_pair = [&](std::pair<hipEvent_t, hipEvent_t>*& out) -> int {
+        if (ev_used == d->ev_pool.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            d->ev_pool.emplace_back(e0, e1);
         }
+        out = &d->ev_pool[ev_used++];
         return MCPT_OK;
     };
+    const int kSyncEvery = 4;
     for (int64_t first = 0; first < npx; first += chunk_slots) {
         const int n_slots = int(std::min<int64_t>(chunk_slots, npx - first));
-        unsigned int n_hit = 0;
-        HIP_TRY(hipMemsetAsync(d->wf_counts, 0, sizeof(WfCounts), st));
-        launch_hit_slots(d->hits, int(first), n_slots, d->hit_slots, &d->wf_counts->n_next, st);
+        HIP_TRY(hipMemsetAsync(d->wf_counts, 0, sizeof(WfCounts) * MCPT_WF_COUNT_SLOTS, st));
+        launch_hit_slots(d->hits, int(first), n_slots, d->hit_slots, &d->wf_counts[0].n_next, st);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&n_hit, &d->wf_counts->n_next, sizeof n_hit, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if ((rc = read_pending())) return rc;
-        long long n_prev = (long long)n_hit * spp;
+        long long n_upper = (long long)n_slots * spp;        // upper bound of the live paths, refined at every look
         a.first_slot = int(first);
         a.in = A; a.out = B;
-        for (int depth = 0; n_prev > 0; depth++) {
+        for (int depth = 0; depth < MCPT_MAX_DEPTH && n_upper > 0; depth++) {
             a.depth = depth;
-            HIP_TRY(hipMemsetAsync(d->wf_counts, 0, sizeof(WfCounts), st));
-            launch_wf_logic(d->ds, a, n_prev, depth == 0, st);
+            a.counts_in = &d->wf_counts[depth]; a.count_mul = depth == 0 ? unsigned(spp) : 1u;
+            a.counts = &d->wf_counts[depth + 1];
+            launch_wf_logic(d->ds, a, n_upper, depth == 0, st);
             HIP_TRY(hipGetLastError());
-            unsigned int n_next = 0;
-            HIP_TRY(hipMemcpyAsync(&n_next, &d->wf_counts->n_next, sizeof n_next, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if ((rc = read_pending())) return rc;
-            if (n_next == 0) break;
-            if (stats) HIP_TRY(hipEventRecord(d->ev[2], st));
-            launch_wf_trace(d->ds, a, n_next, fast, d->queue, d->slow_list, d->slow_cap, st);
+            std::pair<hipEvent_t, hipEvent_t>* pr = nullptr;
+            if (stats) { if ((rc = next_pair(pr))) return rc; HIP_TRY(hipEventRecord(pr->first, st)); }
+            launch_wf_trace(d->ds, a, n_upper, fast, d->queue, d->slow_list, d->slow_cap, st);
             HIP_TRY(hipGetLastError());
-            if (stats) { HIP_TRY(hipEventRecord(d->ev[3], st)); pending = true; }
+            if (stats) HIP_TRY(hipEventRecord(pr->second, st));
             launches++;
             std::swap(a.in, a.out);
-            n_prev = n_next;
+            if ((depth + 1) % kSyncEvery == 0) {
+                unsigned int n_now = 0;
+                HIP_TRY(hipMemcpyAsync(&n_now, &d->wf_counts[depth + 1].n_next, sizeof n_now, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                n_upper = n_now;
+            }
+        }
+        // paths still alive at the depth cap cannot exist: logic(MAX_DEPTH-1) emits no bounce ray; a last logic pass resolves them
+        if (n_upper > 0) {
+            a.depth = MCPT_MAX_DEPTH;
+            a.counts_in = &d->wf_counts[MCPT_MAX_DEPTH]; a.count_mul = 1u; a.counts = &d->wf_counts[MCPT_MAX_DEPTH + 1];
+            launch_wf_logic(d->ds, a, n_upper, false, st);
+            HIP_TRY(hipGetLastError());
         }
         launch_fold_samples(d->rad, d->pixels, d->hits, int(first), n_slots, spp, d_img, st);
         HIP_TRY(hipGetLastError());
     }
-    if (pending) {
-        HIP_TRY(hipEventSynchronize(d->ev[3]));
-        if ((rc = read_pending())) return rc;
+    if (stats) {
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < ev_used; i++) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev_pool[i].first, d->ev_pool[i].second));
+            ms_trace += ms;
+        }
     }
     return MCPT_OK;
 }

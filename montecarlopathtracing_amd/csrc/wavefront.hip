@@ -1,6 +1,8 @@
 // Wavefront integrator kernels (see wavefront.hpp).  -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dev_common.hpp"
 #include "shade_common.hpp"
 #include "trace_persistent.hpp"
@@ -51,8 +53,9 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfSta
 // ---------------------------------------------------------------------------------------------- logic kernel
 // One thread per path position of the previous iteration.  FIRST: positions enumerate (hit slot, k).
 template <bool FIRST>
-__global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a, long long n_prev)
+__global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a)
 {
+    const long long n_prev = (long long)a.counts_in->n_next * a.count_mul;
     __shared__ unsigned int wave_tot[4];
     __shared__ unsigned int block_base;
     const long long cap = a.cap;
@@ -303,9 +306,19 @@ struct WfRaySource {
 };
 
 // persistent fast walk
-__global__ void __launch_bounds__(256, 3) k_wf_trace(DScene S, WfArgs a, long long n_paths, TraceQueue* queue, long long* slow_list,
-                                                  unsigned int slow_cap, long long chunk)
+__device__ __forceinline__ long long wf_chunk(long long total)
 {
+    const long long waves = (long long)gridDim.x * 4;
+    long long c = total / (waves * 4);
+    c = (c / 64) * 64;
+    return c < 64 ? 64 : (c > 2048 ? 2048 : c);
+}
+
+__global__ void __launch_bounds__(256, 3) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap)
+{
+    const long long n_paths = a.counts->n_next;
+    if (n_paths == 0) return;
+    const long long chunk = wf_chunk(n_paths * (a.nl + 1));
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
     WfRaySource src; src.a = a; src.n_paths = n_paths;
@@ -319,9 +332,10 @@ __global__ void __launch_bounds__(256, 3) k_wf_trace(DScene S, WfArgs a, long lo
     flush_stats(a.ctr, ls);
 }
 
-__global__ void __launch_bounds__(256) k_wf_trace_slow(DScene S, WfArgs a, long long n_paths, const TraceQueue* queue, const long long* slow_list,
-                                                       unsigned int slow_cap)
+__global__ void __launch_bounds__(256) k_wf_trace_slow(DScene S, WfArgs a, const TraceQueue* queue, const long long* slow_list, unsigned int slow_cap)
 {
+    const long long n_paths = a.counts->n_next;
+    if (n_paths == 0 || queue->slow_count == 0) return;
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
@@ -331,8 +345,9 @@ __global__ void __launch_bounds__(256) k_wf_trace_slow(DScene S, WfArgs a, long 
 }
 
 // reference-shaped walk for every ray (MCPT_TRACE_REFERENCE): one thread per slot
-__global__ void __launch_bounds__(256) k_wf_trace_reference(DScene S, WfArgs a, long long n_paths)
+__global__ void __launch_bounds__(256) k_wf_trace_reference(DScene S, WfArgs a)
 {
+    const long long n_paths = a.counts->n_next;
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     const long long total = src.total();
     LaneStats ls;
@@ -374,12 +389,23 @@ static unsigned grid_for(long long n, int block, unsigned cap_blocks)
     return (unsigned)(b > cap_blocks ? cap_blocks : b);
 }
 
-void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_prev, bool first, hipStream_t st)
+int persistent_grid(const void* kernel);
+
+// A resident-size grid whose blocks stride over the paths: starting a block of this kernel is expensive (large kernarg,
+// 160+ VGPRs, scratch), so 768 long-lived blocks beat 16 k short ones by 15 % of a frame at N=1 and 30 % at one eighth
+// of a frame (measured: MCPT_LOGIC_GRID sweep).
+void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st)
 {
-    if (n_prev <= 0) return;
-    const unsigned g = grid_for(n_prev, 256, 256u * 64u);
-    if (first) hipLaunchKernelGGL(k_wf_logic<true>, dim3(g), dim3(256), 0, st, S, a, n_prev);
-    else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a, n_prev);
+    if (n_upper <= 0) return;
+    static const unsigned forced = [] { const char* e = std::getenv("MCPT_LOGIC_GRID"); return e ? unsigned(std::atoi(e)) : 0u; }();
+    static unsigned cap_first = 0, cap_rest = 0;
+    if (!cap_first) {
+        cap_first = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<true>)));
+        cap_rest = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<false>)));
+    }
+    const unsigned g = grid_for(n_upper, 256, first ? cap_first : cap_rest);
+    if (first) hipLaunchKernelGGL(k_wf_logic<true>, dim3(g), dim3(256), 0, st, S, a);
+    else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a);
 }
 
 int persistent_grid(const void* kernel)
@@ -406,13 +432,13 @@ long long persistent_chunk(long long total, int grid_blocks)
     return c;
 }
 
-void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, TraceQueue* queue, long long* slow_list,
+void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool fast, TraceQueue* queue, long long* slow_list,
                      unsigned int slow_cap, hipStream_t st)
 {
-    if (n_paths <= 0) return;
-    const long long total = n_paths * (a.nl + 1);
+    if (n_upper <= 0) return;
+    const long long total = n_upper * (a.nl + 1);
     if (!fast) {
-        hipLaunchKernelGGL(k_wf_trace_reference, dim3(grid_for(total, 256, 1u << 30)), dim3(256), 0, st, S, a, n_paths);
+        hipLaunchKernelGGL(k_wf_trace_reference, dim3(grid_for(total, 256, 1u << 20)), dim3(256), 0, st, S, a);
         return;
     }
     static int grid = 0;
@@ -420,14 +446,8 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool f
     const long long blocks_needed = (total + 255) / 256;
     const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, n_paths, queue, slow_list, slow_cap, persistent_chunk(total, g));
-    hipLaunchKernelGGL(k_wf_trace_slow, dim3(256), dim3(256), 0, st, S, a, n_paths, queue, slow_list, slow_cap);
-}
-
-void launch_wf_trace_reference(const DScene& S, const WfArgs& a, long long n_paths, hipStream_t st)
-{
-    if (n_paths <= 0) return;
-    hipLaunchKernelGGL(k_wf_trace_reference, dim3(grid_for(n_paths * (a.nl + 1), 256, 1u << 30)), dim3(256), 0, st, S, a, n_paths);
+    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
+    hipLaunchKernelGGL(k_wf_trace_slow, dim3(256), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
 }
 
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)

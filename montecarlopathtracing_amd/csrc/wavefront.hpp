@@ -42,10 +42,11 @@ struct TraceQueue {                 // persistent trace kernels; device words, z
     unsigned int pad[13];
 };
 
-struct WfCounts {           // device-side counters of one iteration
-    unsigned int n_next;    // paths alive after compaction
+struct WfCounts {           // one per iteration, on the device: slot 0 = hit pixels of the chunk, slot d+1 = paths alive after
+    unsigned int n_next;    // logic(d).  Kernels read their input count from the previous slot, so the host need not know it.
     unsigned int pad[15];
 };
+#define MCPT_WF_COUNT_SLOTS 72
 
 struct WfArgs {
     WfState in, out;
@@ -59,7 +60,9 @@ struct WfArgs {
     const double* dirs;         // primary directions per pixel
     int first_slot;
     double* rad;                // [chunk samples][3] finished radiance
-    WfCounts* counts;           // counts[0] = this iteration's output
+    WfCounts* counts;           // this iteration's output slot
+    const WfCounts* counts_in;  // the slot holding this iteration's input count
+    unsigned int count_mul;     // input paths = counts_in->n_next * count_mul (spp for the first pass, 1 afterwards)
     DCounters* ctr;
     const DTri* tris;           // S.tris (material of a shadow ray's hit)
 };
@@ -68,12 +71,13 @@ size_t wf_bytes_per_path(int nl);
 // carve the workspace; returns false if it does not fit
 bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& a, WfState& b, WfRays& r);
 
-void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_prev, bool first, hipStream_t st);
-void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_paths, bool fast, TraceQueue* queue, long long* slow_list,
+// n_upper: host-side upper bound of the input count (sizes the grid only)
+void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st);
+void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool fast, TraceQueue* queue, long long* slow_list,
                      unsigned int slow_cap, hipStream_t st);
-void launch_wf_trace_reference(const DScene& S, const WfArgs& a, long long n_paths, hipStream_t st);
 int persistent_grid(const void* kernel);
 long long persistent_chunk(long long total, int grid_blocks);
+
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st);
 void launch_zero_rad(double* rad, long long n_doubles, hipStream_t st);
 

@@ -169,8 +169,10 @@ def test_tile_partition_is_a_partition(mcpt):
         assert max(sizes) - min(sizes) <= 32 * 8 * 2
     px = sc.owned_pixels(1, 2, tile_w=4, tile_h=4)
     y, x = px // 130, px % 130
-    tiles_x = (130 + 3) // 4
-    assert np.all(((y // 4) * tiles_x + x // 4) % 2 == 1)
+    assert np.all(((x // 4) + 1 * (y // 4)) % 2 == 1)            # world 2: shift 1
+    px = sc.owned_pixels(3, 8)
+    y, x = px // 130, px % 130
+    assert np.all(((x // 32) + 5 * (y // 8)) % 8 == 3)           # world 8: shift 5 (first >= 4 coprime with 8)
     with pytest.raises(mcpt.McptError):
         sc.owned_pixels(3, 2)
 
