@@ -91,6 +91,7 @@ struct mcpt_device {
     TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
     long long* slow_list = nullptr;
     unsigned int slow_cap = 1u << 20;
+    long long finish_threshold = 200000;            // paths left at which the finishing pass takes over (MCPT_FINISH_PATHS)
 };
 
 extern "C" {
@@ -551,6 +552,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->queue), sizeof(TraceQueue)));
     if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->slow_list), size_t(d->slow_cap) * sizeof(long long)));
+    if (const char* e = std::getenv("MCPT_FINISH_PATHS")) d->finish_threshold = std::atoll(e);
     if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
         const double v = std::atof(gb);
         if (v > 0.01) d->wf_budget_bytes = size_t(v * double(size_t(1) << 30));
@@ -811,17 +813,27 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
         launch_hit_slots(d->hits, int(first), n_slots, d->hit_slots, &d->wf_counts[0].n_next, st);
         HIP_TRY(hipGetLastError());
         long long n_upper = (long long)n_slots * spp;        // upper bound of the live paths, refined at every look
+        double n_grid = double(n_upper);                     // grid-sizing estimate between looks (kernels stride, any grid is correct)
+        bool exact_count = false;                            // n_upper was read from the device after the last logic pass
         a.first_slot = int(first);
         a.in = A; a.out = B;
         for (int depth = 0; depth < MCPT_MAX_DEPTH && n_upper > 0; depth++) {
             a.depth = depth;
             a.counts_in = &d->wf_counts[depth]; a.count_mul = depth == 0 ? unsigned(spp) : 1u;
             a.counts = &d->wf_counts[depth + 1];
-            launch_wf_logic(d->ds, a, n_upper, depth == 0, st);
+            const long long n_launch = std::max<long long>(1, (long long)n_grid);
+            launch_wf_logic(d->ds, a, n_launch, depth == 0, st);
             HIP_TRY(hipGetLastError());
+            if (fast && exact_count && n_upper <= d->finish_threshold) {
+                // few paths left: one lane per path runs them to the end (wavefront.hip: k_wf_finish)
+                launch_wf_finish(d->ds, a, n_upper, st);
+                HIP_TRY(hipGetLastError());
+                n_upper = 0;
+                break;
+            }
             std::pair<hipEvent_t, hipEvent_t>* pr = nullptr;
             if (stats) { if ((rc = next_pair(pr))) return rc; HIP_TRY(hipEventRecord(pr->first, st)); }
-            launch_wf_trace(d->ds, a, n_upper, fast, d->queue, d->slow_list, d->slow_cap, st);
+            launch_wf_trace(d->ds, a, n_launch, fast, d->queue, d->slow_list, d->slow_cap, st);
             HIP_TRY(hipGetLastError());
             if (stats) HIP_TRY(hipEventRecord(pr->second, st));
             launches++;
@@ -831,7 +843,9 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
                 HIP_TRY(hipMemcpyAsync(&n_now, &d->wf_counts[depth + 1].n_next, sizeof n_now, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 n_upper = n_now;
-            }
+                n_grid = double(n_now);
+                exact_count = true;
+            } else { n_grid *= 0.75; exact_count = false; }   // paths die at >= 40 % per bounce (Russian roulette 0.6)
         }
         // paths still alive at the depth cap cannot exist: logic(MAX_DEPTH-1) emits no bounce ray; a last logic pass resolves them
         if (n_upper > 0) {

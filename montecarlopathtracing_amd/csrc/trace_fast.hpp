@@ -95,6 +95,16 @@ __device__ __forceinline__ RayF make_rayf(const DFast& F, const Ray& ray, const 
     return f;
 }
 
+// 1/x to within a few ulp (v_rcp_f64 + two Newton steps).  Only feeds the conservative culling and the certainty bands
+// (2^-48 relative slack = 32 ulp); every value that reaches an output is computed with true divisions.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 struct CwHits { float key[4]; int ref[4]; };
 
 // One step on a compressed node: which children may contain a candidate, sorted by lower bound of entry distance
@@ -146,6 +156,70 @@ __device__ __forceinline__ CwHits cw_step(const CwNode* __restrict__ nd, const R
     MCPT_CSWAP(0, 1) MCPT_CSWAP(2, 3) MCPT_CSWAP(0, 2) MCPT_CSWAP(1, 3) MCPT_CSWAP(1, 2)
 #undef MCPT_CSWAP
     return h;
+}
+
+// One ray per lane, start to finish (while-while over the compressed hierarchy): the same decisions, in the same order
+// per candidate, as the persistent engine -- used where only a few thousand rays remain and a launch per bounce would
+// cost more than the rays themselves.  stack: this lane's LDS words, stack[i * stride].
+__device__ __forceinline__ bool trace_lane_fast(const DScene& S, const Ray& r, Hit& best, Work& w, int* __restrict__ stack, int stride)
+{
+    const DFast& F = S.fast;
+    if (!fast_path_ok(F, r)) return trace_closest(S, r, best, w);
+    const CwNode* __restrict__ nodes = F.cw;
+    const DTri* __restrict__ tris = F.tris;
+    const V3 rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+    const double rmax = fmax(fmax(fabs(rcp.x), fabs(rcp.y)), fabs(rcp.z));
+    const double scale = fmax(fmax(F.absmax, fabs(r.o.x)), fmax(fabs(r.o.y), fabs(r.o.z)));
+    const double margin = rmax <= 1e6 ? 1.0000001e-9 * scale * rmax : __builtin_inf();
+    const RayF rf = make_rayf(F, r, rcp);
+    double limit = __builtin_inf();
+    float limit_f = __builtin_inff();
+    bool found = false;
+    best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
+    int sp = 0, cur = 0;
+    for (;;) {
+        while (cur >= 0) {
+            w.nodes++;
+            const CwHits h = cw_step(nodes + cur, rf, limit_f);
+            if (h.ref[3] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[3]; sp++; }
+            if (h.ref[2] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[2]; sp++; }
+            if (h.ref[1] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[1]; sp++; }
+            cur = h.ref[0];
+            if (cur == MCPT_FAST_EMPTY && sp > 0) { sp--; cur = stack[sp * stride]; }
+        }
+        if (cur == MCPT_FAST_EMPTY) break;
+        const int ref = -1 - cur;
+        const int first = ref >> 4, count = (ref & 7) + 1;
+        for (int i = 0; i < count; i++) {
+            const DTri* tr = tris + first + i;
+            V3 p;
+            w.tris++;
+            if (!tri_hit(tr, r, p)) continue;
+            double lo[3], hi[3];
+            lo[0] = dmin3(tr->v1[0], tr->v2[0], tr->v3[0]); hi[0] = dmax3(tr->v1[0], tr->v2[0], tr->v3[0]);
+            lo[1] = dmin3(tr->v1[1], tr->v2[1], tr->v3[1]); hi[1] = dmax3(tr->v1[1], tr->v2[1], tr->v3[1]);
+            lo[2] = dmin3(tr->v1[2], tr->v2[2], tr->v3[2]); hi[2] = dmax3(tr->v1[2], tr->v2[2], tr->v3[2]);
+            const Slab s = slab_interval(lo, hi, r.o, rcp);
+            bool pass = false;
+            if (!(s.exit < 0.0)) {
+                if (s.entry <= 0.0) pass = true;
+                else if (s.entry + s.entry * 0x1p-48 <= s.exit) pass = true;
+                else if (s.entry > s.exit + s.exit * 0x1p-48) pass = false;
+                else pass = box_hit_exact(lo, hi, r);
+            }
+            if (!pass) continue;
+            const double t = (p.x - r.o.x) / r.d.x;
+            const int k = tr->leaf;
+            if (t > 0 && (!found || t < best.t || (t == best.t && k < best.leaf))) {
+                found = true; best.leaf = k; best.t = t; best.p = p;
+                limit = t + margin;
+                limit_f = __double2float_ru(limit);
+            }
+        }
+        if (sp > 0) { sp--; cur = stack[sp * stride]; }
+        else break;
+    }
+    return found;
 }
 
 }  // namespace mcpt

@@ -26,16 +26,6 @@ namespace mcpt {
 #define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
 #endif
 
-// 1/x to within a few ulp (v_rcp_f64 + two Newton steps).  Only feeds the conservative culling and the certainty bands
-// (2^-48 relative slack = 32 ulp); every value that reaches an output is computed with true divisions.
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
-}
-
 // Src must provide:  long long total() const;
 //                    bool fetch(long long q, Ray& r) const;        // false: slot holds no ray (loads may be speculative)
 //                    void store(long long q, bool hit, const Hit& h) const;

@@ -5,6 +5,7 @@
 
 #include "dev_common.hpp"
 #include "shade_common.hpp"
+#include "shade_path.hpp"
 #include "trace_persistent.hpp"
 #include "wavefront.hpp"
 
@@ -363,6 +364,61 @@ __global__ void __launch_bounds__(256) k_wf_trace_reference(DScene S, WfArgs a)
     flush_stats(a.ctr, ls);
 }
 
+// ---------------------------------------------------------------------------------------------- finishing pass
+// When only a few thousand paths are left, a launch pair per bounce costs more than the paths: every remaining path is run
+// to its end by one lane.  Input = the state logic(depth) has just written (its rays not yet traced): trace them, resolve the
+// vertex exactly as the next logic pass would, then continue with the shared path loop (shade_path_from).
+__global__ void __launch_bounds__(256) k_wf_finish(DScene S, WfArgs a)
+{
+    __shared__ int lds_stack[MCPT_FAST_STACK * 256];
+    const long long n = a.counts->n_next;
+    const long long cap = a.cap;
+    const int nl = a.nl;
+    LaneStats ls;
+    Work w = {0, 0};
+    int* stack = lds_stack + threadIdx.x;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
+        const int id = a.out.id[j];
+        V3 T = ldc(a.out.T, cap, j), L = ldc(a.out.L, cap, j);
+        V3 L_dir = mk(0, 0, 0);
+        for (int l = 0; l < nl; l++) {
+            const int expect = a.out.expect[(long long)l * cap + j];
+            if (expect == -2) continue;
+            Ray r;
+            r.o = ldc(a.rays.o + (long long)l * 3 * cap, cap, j);
+            r.d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j);
+            Hit h;
+            const bool ok = trace_lane_fast(S, r, h, w, stack, 256);
+            const bool vis = (ok ? S.tris[h.leaf].material : -1) == expect;
+            const V3 c = ldc(a.out.c + (long long)l * 3 * cap, cap, j);
+            L_dir.x += vis ? c.x : c.x * 0.0;
+            L_dir.y += vis ? c.y : c.y * 0.0;
+            L_dir.z += vis ? c.z : c.z * 0.0;
+        }
+        L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
+        double out[3] = {L.x, L.y, L.z};
+        const int bt = a.out.btype[j];
+        if (bt >= 0) {
+            Ray r;
+            r.o = ldc(a.rays.o + (long long)nl * 3 * cap, cap, j);
+            r.d = ldc(a.rays.d + (long long)nl * 3 * cap, cap, j);
+            Hit h;
+            if (trace_lane_fast(S, r, h, w, stack, 256)) {
+                const V3 wgt = ldc(a.out.w, cap, j);
+                T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
+                const int slot = a.first_slot + id / a.spp;
+                RngKey key;
+                key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
+                key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); key.sample = (uint32_t)(id % a.spp);
+                shade_path_from<true>(S, key, (uint32_t)a.depth + 1u, T, L, neg(r.d), bt, h, out, ls, stack, 256);
+            }
+        }
+        a.rad[(size_t)id * 3] = out[0]; a.rad[(size_t)id * 3 + 1] = out[1]; a.rad[(size_t)id * 3 + 2] = out[2];
+    }
+    ls.nodes += w.nodes; ls.tris += w.tris;
+    flush_stats(a.ctr, ls);
+}
+
 // slots of this chunk whose primary ray hit something, in slot order within a wave
 __global__ void k_hit_slots(const PrimaryHit* __restrict__ hits, int first_slot, int n_slots, int32_t* __restrict__ hit_slots, unsigned int* count)
 {
@@ -403,7 +459,8 @@ void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool f
         cap_first = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<true>)));
         cap_rest = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<false>)));
     }
-    const unsigned g = grid_for(n_upper, 256, first ? cap_first : cap_rest);
+    // small inputs get small grids (>= 1024 paths per block): every wave that starts costs a few atomics on shared counters
+    unsigned g = grid_for(n_upper, 1024, first ? cap_first : cap_rest);
     if (first) hipLaunchKernelGGL(k_wf_logic<true>, dim3(g), dim3(256), 0, st, S, a);
     else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a);
 }
@@ -443,11 +500,18 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
     }
     static int grid = 0;
     if (!grid) grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace));
-    const long long blocks_needed = (total + 255) / 256;
+    // a wave that starts pays one atomic on the queue head and a few on the counters: give every block >= 2048 rays
+    const long long blocks_needed = (total + 2047) / 2048;
     const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
     hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
-    hipLaunchKernelGGL(k_wf_trace_slow, dim3(256), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
+    hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 64 ? g : 64), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
+}
+
+void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st)
+{
+    if (n_upper <= 0) return;
+    hipLaunchKernelGGL(k_wf_finish, dim3(grid_for(n_upper, 256, 1024)), dim3(256), 0, st, S, a);
 }
 
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)

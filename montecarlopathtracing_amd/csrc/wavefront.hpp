@@ -75,6 +75,7 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& a, WfSta
 void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st);
 void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool fast, TraceQueue* queue, long long* slow_list,
                      unsigned int slow_cap, hipStream_t st);
+void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st);
 int persistent_grid(const void* kernel);
 long long persistent_chunk(long long total, int grid_blocks);
 
