@@ -16,17 +16,30 @@ from conftest import ROOT  # noqa: E402
 
 REL_TOL = 1e-9
 
+# Discrete flips.  The reference starts refraction / total-internal-reflection rays exactly on the surface they leave
+# (pathTracing.cpp:102,109: no 0.01 offset), so whether such a ray re-hits its own triangle is decided by the sign of a t_x
+# that is pure rounding noise -- any last-bit difference upstream (device libm vs glibc) flips it.  Scenes without Ni > 1
+# only flip when a uniform lands within an ulp of a threshold.
+FLIP_BUDGET = {"cornell-box": 1e-4, "veach-mis": 1e-4, "glassroom": 1e-2}
+
 
 def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-@pytest.fixture(scope="module", params=["cornell-box", "veach-mis"])
+EXTRA = os.path.join(ROOT, "tests", "scenes_extra") + os.sep
+
+
+# glassroom (tests/scenes_extra, CRLF files): refraction incl. total internal reflection (Ni 1.5), a Phong lobe (Ns 60), a
+# textured quad, and a second light larger than the first (the frozen light-area distribution Q1 then never reaches most of
+# it) -- the branches the two shipped scenes do not execute.
+@pytest.fixture(scope="module", params=["cornell-box", "veach-mis", "glassroom"])
 def pair(request, oracle, mcpt):
     name = request.param
     w, h = (160, 90)
-    osc = oracle.OracleScene(SCENES + name, texture_dir=SCENES, width=w, height=h)
-    sc = mcpt.Scene(SCENES, name, width=w, height=h)
+    base = EXTRA if name == "glassroom" else SCENES
+    osc = oracle.OracleScene(base + name, texture_dir=base, width=w, height=h)
+    sc = mcpt.Scene(base, name, width=w, height=h)
     dev = mcpt.Device(sc, 0)
     yield name, osc, sc, dev
     dev.close()
@@ -117,8 +130,10 @@ def test_sample_radiance(pair, oracle, mcpt):
     scale = np.maximum(np.abs(o).max(axis=1), 1e-12)
     err = np.abs(g - o).max(axis=1) / scale
     flips = int((err > REL_TOL).sum())
-    assert flips <= max(1, n // 10000 + 1), "radiance mismatch on %d/%d samples (max rel %.3e)" % (flips, n, err.max())
+    assert flips <= max(1, int(n * FLIP_BUDGET[name]) + 1), "radiance mismatch on %d/%d samples (max rel %.3e)" % (flips, n, err.max())
     assert np.abs(o).sum() > 0
+    same = err <= REL_TOL
+    assert abs(g[same].sum() - o[same].sum()) <= 1e-9 * abs(o[same]).sum()
 
 
 @pytest.mark.parametrize("pipeline", ["wavefront", "megakernel"])
@@ -133,12 +148,14 @@ def test_image_matches_oracle(pair, oracle, mcpt, pipeline):
     scale = np.maximum(np.abs(ref), 1e-6)
     rel = np.abs(img - ref) / scale
     bad = int((rel > 1e-6).sum())      # float accumulator: 1 ulp of fp32 ~ 6e-8
-    assert bad <= max(3, img.size // 20000), "%d pixel channels differ (max rel %.3e)" % (bad, rel.max())
-    # same work was done
-    assert st.rays_shadow + st.shadow_skipped == ost.rays_shadow and st.rays_bounce == ost.rays_bounce
-    assert st.shade_calls == ost.shade_calls and st.samples == ost.samples
-    assert np.array_equal(mcpt.imshow_rgb8(img) != oracle.quantize(ref), np.zeros_like(img, dtype=bool)) or \
-        int((mcpt.imshow_rgb8(img) != oracle.quantize(ref)).sum()) <= 8
+    budget = max(3, int(img.size * spp * FLIP_BUDGET[name] * 0.5))
+    assert bad <= budget, "%d pixel channels differ (max rel %.3e)" % (bad, rel.max())
+    assert abs(img.mean() - ref.mean()) <= 2e-3 * ref.mean()
+    if name != "glassroom":            # same work was done (a flipped path does different work)
+        assert st.rays_shadow + st.shadow_skipped == ost.rays_shadow and st.rays_bounce == ost.rays_bounce
+        assert st.shade_calls == ost.shade_calls
+    assert st.samples == ost.samples
+    assert int((mcpt.imshow_rgb8(img) != oracle.quantize(ref)).sum()) <= max(8, budget)
 
 
 def test_pipelines_agree_bitwise(pair, mcpt):
