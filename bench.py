@@ -141,11 +141,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # MCPT_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a one-GPU box -- every rank uses GPU 0 and the gather runs over
+    # gloo on host copies (RCCL refuses two ranks on one device).  Not a measurement configuration.
+    share_gpu = os.environ.get("MCPT_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     tdev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
 
     if args.scene == "synthetic":
         from montecarlopathtracing_amd import synthetic
@@ -161,7 +169,7 @@ def main():
         scene_dir = write_scene_dir(args.scene, args.width, args.height)
         scene = M.Scene(scene_dir, args.scene)
         dev = M.Device(scene, local_rank)
-    rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev)
+    rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev, stage_on_cpu=share_gpu)
     if args.sim_world > 1:          # one rank's share of an N-way partition, no communication
         class _Sim:
             def __init__(self):
@@ -193,8 +201,9 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
+    red_dev = torch.device("cpu") if share_gpu else tdev
     vals = torch.tensor([elapsed] + [float(tot[k]) for k in ("rays", "node_visits", "tri_tests", "samples", "launches")] + [tot["ms_trace"]],
-                        dtype=torch.float64, device=tdev)
+                        dtype=torch.float64, device=red_dev)
     if world > 1:
         mx = vals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)

@@ -14,18 +14,23 @@ def owned_counts(scene, world, tile_w=0, tile_h=0):
     return [int(scene.owned_pixels(r, world, tile_w, tile_h).shape[0]) for r in range(world)]
 
 
-def gather_frame(local_flat, pixels, counts, rank, world, group=None):
+def gather_frame(local_flat, pixels, counts, rank, world, group=None, stage_on_cpu=False):
     """local_flat: [H*W, 3] tensor holding this rank's pixels at their frame positions; pixels: LongTensor of the
-    owned indices (same device).  Returns the assembled [H*W, 3] frame on rank 0 (None elsewhere)."""
+    owned indices (same device).  Returns the per-rank compact buffers on rank 0 (None elsewhere).
+    stage_on_cpu: run the collective on host copies (gloo rehearsals with several ranks sharing one GPU)."""
     if world == 1:
         return local_flat
     nmax = max(counts)
     send = torch.zeros((nmax, 3), dtype=local_flat.dtype, device=local_flat.device)
     send[: pixels.shape[0]] = local_flat.index_select(0, pixels)
+    if stage_on_cpu:
+        send = send.cpu()
     bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
     dist.gather(send, bufs, dst=0, group=group)
     if rank != 0:
         return None
+    if stage_on_cpu:
+        bufs = [b.to(local_flat.device) for b in bufs]
     return bufs
 
 
@@ -39,8 +44,9 @@ def scatter_into_frame(frame_flat, bufs, pixel_lists):
 class DistributedRenderer:
     """generateImg over `world` GPUs of one node; rank r drives GPU `local_rank`."""
 
-    def __init__(self, scene, device, rank=0, world=1, tile_w=0, tile_h=0, torch_device=None):
+    def __init__(self, scene, device, rank=0, world=1, tile_w=0, tile_h=0, torch_device=None, stage_on_cpu=False):
         self.scene, self.device, self.rank, self.world = scene, device, rank, world
+        self.stage_on_cpu = stage_on_cpu
         self.tile_w, self.tile_h = tile_w, tile_h
         self.torch_device = torch_device
         i = scene.info
@@ -62,7 +68,7 @@ class DistributedRenderer:
                                   flags, stats, stream)
         if self.world == 1:
             return self.frame.view(self.H, self.W, 3)
-        bufs = gather_frame(self.frame, self.pixels, self.counts, self.rank, self.world)
+        bufs = gather_frame(self.frame, self.pixels, self.counts, self.rank, self.world, stage_on_cpu=self.stage_on_cpu)
         if self.rank != 0:
             return None
         scatter_into_frame(self.frame, bufs, self.pixel_lists)
