@@ -22,7 +22,6 @@ sys.path.insert(0, ROOT)
 BYTES_PER_NODE = 64      # one compressed 4-wide node (quantised child boxes + child references) per inner step
 BYTES_PER_TRI = 104      # 9 fp64 vertices + 3 fp64 normal + ids of a tested triangle
 BYTES_PER_RAY = 64       # ray origin/direction in, hit record out
-BYTES_PER_SAMPLE = 48    # 24 B radiance written by the shading kernel + 24 B read back by the fold
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -191,7 +190,7 @@ def main():
     sync()
     stats = M.Stats()
     tot = {"rays": 0, "node_visits": 0, "tri_tests": 0, "samples": 0, "ms_trace": 0.0, "launches": 0, "rays_primary": 0,
-           "rays_shadow": 0, "rays_bounce": 0}
+           "rays_shadow": 0, "rays_bounce": 0, "dom_rays": 0, "dom_node_visits": 0, "dom_tri_tests": 0}
     t0 = time.perf_counter()
     frame = None
     for _ in range(args.steps):
@@ -222,9 +221,16 @@ def main():
         value = rays / elapsed / 1e6
         # dominant kernel = k_shade_samples (one launch per pixel chunk); algorithmic bytes of its launches
         prim = tot["rays_primary"]
-        alg_bytes_rank0 = (BYTES_PER_NODE * tot["node_visits"] + BYTES_PER_TRI * tot["tri_tests"] + BYTES_PER_RAY * tot["rays"]
-                           + BYTES_PER_SAMPLE * tot["samples"])
+        # numerator: only what k_wf_trace itself did (its own device counters); the samples term is the radiance the frame writes
+        # and folds, carried here because the contract's per-unit figure includes it
+        alg_bytes_rank0 = (BYTES_PER_NODE * tot["dom_node_visits"] + BYTES_PER_TRI * tot["dom_tri_tests"] + BYTES_PER_RAY * tot["dom_rays"])
         n_launch = max(1, tot["launches"])
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload (bench.py cannot collect PMC itself)
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
+        if args.scene == "cornell-box" and (args.width, args.height, args.spp) == (1280, 720, 256) and world == 1 and os.path.exists(tf):
+            tj = json.load(open(tf))
+            traffic, traffic_src = tj["bytes_per_launch"], "profiles/r01_final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         avg_ms = tot["ms_trace"] / n_launch
         achieved = (alg_bytes_rank0 / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
@@ -240,10 +246,10 @@ def main():
             "rays_per_frame": rays / steps, "samples_per_frame": samples / steps,
             "nodes_per_ray": nodes / max(1.0, rays), "tris_per_ray": tris / max(1.0, rays),
             "roofline": {"bound": "hbm", "kernel": "k_wf_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches": tot["launches"],
                          "algorithmic_bytes_per_launch": alg_bytes_rank0 / n_launch,
-                         "note": "rank-0 launches; bytes = 64 B x node visits + 104 B x triangle tests + 64 B x rays + 48 B x samples, from the run's own device counters; the scene (0.3 MB of nodes, 2 MB of triangles) is cache-resident, see DESIGN.md"},
+                         "note": "rank-0 launches of k_wf_trace; algorithmic bytes = 64 B x inner nodes visited + 104 B x triangles tested + 64 B x rays, counted by the kernel's own device counters in this run; these bytes are served by L1/L2 (0.3 MB of nodes, 2 MB of triangles), HBM traffic is the streamed ray/hit records -- see DESIGN.md 6"},
         }
         if args.save_png and frame is not None:
             img = frame.cpu().numpy()

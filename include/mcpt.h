@@ -61,6 +61,8 @@ typedef struct {
     uint64_t shade_calls, samples;
     uint64_t shadow_skipped;                         /* shadow rays the reference traces although it never uses their answer
                                                         (light behind the surface, pathTracing.cpp:217); not traced here */
+    uint64_t dom_rays, dom_node_visits, dom_tri_tests; /* the share of the above done inside the dominant kernel (k_wf_trace):
+                                                        numerator of its roofline */
     double   ms_trace, ms_total;                     /* device time of the dominant kernel / whole call (HIP events) */
     int32_t  launches;                               /* launches of the dominant kernel */
     int32_t  max_depth;

@@ -29,7 +29,8 @@ class SceneInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("shade_calls", C.c_uint64),
-                ("samples", C.c_uint64), ("shadow_skipped", C.c_uint64), ("ms_trace", C.c_double), ("ms_total", C.c_double),
+                ("samples", C.c_uint64), ("shadow_skipped", C.c_uint64), ("dom_rays", C.c_uint64),
+                ("dom_node_visits", C.c_uint64), ("dom_tri_tests", C.c_uint64), ("ms_trace", C.c_double), ("ms_total", C.c_double),
                 ("launches", C.c_int32), ("max_depth", C.c_int32)]
 
     @property

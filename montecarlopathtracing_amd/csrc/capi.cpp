@@ -633,6 +633,7 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
     s->rays_primary = c.rays_primary; s->rays_shadow = c.rays_shadow; s->rays_bounce = c.rays_bounce;
     s->node_visits = c.node_visits; s->tri_tests = c.tri_tests; s->shade_calls = c.shade_calls; s->samples = c.samples;
     s->shadow_skipped = c.shadow_skipped;
+    s->dom_rays = c.trace_rays; s->dom_node_visits = c.trace_nodes; s->dom_tri_tests = c.trace_tris;
     if (std::getenv("MCPT_PRINT_DIAG")) {
         const double tot = double(c.pad[5] + c.pad[6] + c.pad[7]);
         std::fprintf(stderr, "trace diag: inner iters %llu lanes %.1f/64 | tri iters %llu lanes %.1f/64 | idle lanes/iter %.1f | wave time: refill %.1f%% inner %.1f%% tri %.1f%% | cycles/inner iter %.0f cycles/tri iter %.0f\n",

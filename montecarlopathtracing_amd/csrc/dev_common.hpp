@@ -125,6 +125,7 @@ __device__ __forceinline__ V3 barycentric(V3 v1, V3 v2, V3 v3, V3 p)
 struct Hit { int leaf; double t; V3 p; };
 struct Work {
     uint32_t nodes, tris;
+    uint32_t rays = 0;          // rays started by the persistent engine
 #ifdef MCPT_TRACE_DIAG
     unsigned long long diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // inner iters, inner lanes, tri iters, tri lanes, idle lanes, cycles refill/inner/tri
 #endif

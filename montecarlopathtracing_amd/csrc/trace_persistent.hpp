@@ -127,6 +127,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                         nr.d = mk(raybuf[3 * 64 + e], raybuf[4 * 64 + e], raybuf[5 * 64 + e]);
                         const long long q = lds_base + e;
                         if (fast_path_ok(F, nr)) {
+                            w.rays++;
                             slot = q; r = nr;
                             rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
                             const double rmax = fmax(fmax(fabs(rcp.x), fabs(rcp.y)), fabs(rcp.z));     // = 1 / min|d_k|

@@ -327,6 +327,10 @@ __global__ void __launch_bounds__(256, 3) k_wf_trace(DScene S, WfArgs a, TraceQu
     Work w = {0, 0};
     trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w);
     ls.nodes = w.nodes; ls.tris = w.tris;
+    if (a.ctr) {        // the dominant kernel's own work, for its roofline
+        const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&a.ctr->trace_nodes, tn); atomicAdd(&a.ctr->trace_tris, tt); atomicAdd(&a.ctr->trace_rays, tr); }
+    }
 #ifdef MCPT_TRACE_DIAG
     if ((threadIdx.x & 63) == 0 && a.ctr) for (int i = 0; i < 8; i++) atomicAdd(&a.ctr->pad[i], w.diag[i]);
 #endif
