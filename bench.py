@@ -164,6 +164,13 @@ def main():
             print("synthetic scene: %d triangles, generate+create %.1f s, device build %.1f s" %
                   (scene.info.num_faces, t_dev - t_gen, time.perf_counter() - t_dev), file=sys.stderr)
         scene_dir = None
+    elif args.scene == "interior":
+        # substitute for configs[3] (bedroom.obj is not shipped by the reference): generated textured interior, ~204 k triangles
+        from montecarlopathtracing_amd import synthetic
+        scene_dir = tempfile.mkdtemp(prefix="mcpt_interior_") + os.sep
+        synthetic.write_interior(scene_dir, "interior", width=args.width, height=args.height)
+        scene = M.Scene(scene_dir, "interior")
+        dev = M.Device(scene, local_rank)
     else:
         scene_dir = write_scene_dir(args.scene, args.width, args.height)
         scene = M.Scene(scene_dir, args.scene)
@@ -254,7 +261,7 @@ def main():
         if args.save_png and frame is not None:
             img = frame.cpu().numpy()
             M.write_png(args.save_png, M.imshow_rgb8(img))
-        if world == 1 and not args.no_cpu_baseline and scene_dir is not None:
+        if world == 1 and not args.no_cpu_baseline and scene_dir is not None and args.scene != "interior":
             cb = cpu_baseline(scene_dir, args.scene, args.seed)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu_mrays"] = value / cb["value"]
