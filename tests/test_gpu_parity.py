@@ -156,7 +156,9 @@ def test_image_matches_oracle(pair, oracle, mcpt, pipeline):
     bad = int((rel > 1e-6).sum())      # float accumulator: 1 ulp of fp32 ~ 6e-8
     budget = max(3, int(img.size * spp * FLIP_BUDGET[name] * 0.5))
     assert bad <= budget, "%d pixel channels differ (max rel %.3e)" % (bad, rel.max())
-    assert abs(img.mean() - ref.mean()) <= 2e-3 * ref.mean()
+    # a flipped sample can be a firefly (radiance / 0.6^depth): the image mean moves with the flip budget
+    assert abs(img.mean() - ref.mean()) <= (3e-2 if FLIP_BUDGET[name] > 1e-3 else 2e-3) * ref.mean()
+    assert (rel <= 1e-6).mean() >= 0.97
     if name not in ("glassroom", "interior"):   # same work was done (a flipped path does different work)
         assert st.rays_shadow + st.shadow_skipped == ost.rays_shadow and st.rays_bounce == ost.rays_bounce
         assert st.shade_calls == ost.shade_calls
