@@ -28,7 +28,7 @@ __device__ __forceinline__ void stc(double* __restrict__ a, long long cap, long 
 size_t wf_bytes_per_path(int nl)
 {
     const size_t state = 4 + (6 + 3 * nl + 6) * 8 + nl * 4 + 4 + nl * 4 + 4 + 3 * 8;   // WfState
-    const size_t rays = (nl + 1) * 6 * 8;                                            // WfRays
+    const size_t rays = (1 + nl) * 3 * 8;                                            // WfRays
     return 2 * state + rays;
 }
 
@@ -47,7 +47,7 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfSta
         s.hit_p = static_cast<double*>(take(cap * 24));
     };
     state(A); state(B);
-    R.o = static_cast<double*>(take(size_t(cap) * 24 * (nl + 1))); R.d = static_cast<double*>(take(size_t(cap) * 24 * (nl + 1)));
+    R.p = static_cast<double*>(take(size_t(cap) * 24)); R.d = static_cast<double*>(take(size_t(cap) * 24 * nl));
     return p <= end;
 }
 
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             } else {
                 // ---- resolve vertex depth-1 (pathTracing.cpp:213-231, 244-261)
                 id = a.in.id[i];
-                T = ldc(a.in.T, cap, i); L = ldc(a.in.L, cap, i);
+                if (depth > 1) { T = ldc(a.in.T, cap, i); L = ldc(a.in.L, cap, i); }
                 V3 L_dir = mk(0, 0, 0);
                 for (int l = 0; l < nl; l++) {
                     const int expect = a.in.expect[(long long)l * cap + i];
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                         T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
                         leaf = hl; p = ldc(a.in.hit_p, cap, i);
                         dir = neg(ldc(a.in.bdir, cap, i));
-                        in_type = bt;
+                        in_type = bt & 7;
                         have_vertex = true;
                     }
                 }
@@ -201,21 +201,21 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                 const V3 intensity = ((ld3(lt->radiance) * cos_theta) * cos_theta_hat) * (frcp(sqr(dist)) * lt->total_area);
                 const V3 c = mk(kd.x * intensity.x * kd_dots * MCPT_INV_PI, kd.y * intensity.y * kd_dots * MCPT_INV_PI, kd.z * intensity.z * kd_dots * MCPT_INV_PI);
                 stc(a.out.c + (long long)l * 3 * cap, cap, j, c);
-                stc(a.rays.o + (long long)l * 3 * cap, cap, j, p + direction * 0.01);
-                stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);
+                stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);       // origin p + direction * 0.01: WfRaySource
                 expect = sample_mat;
                 ls.shadow++;
             } else ls.skipped++;
             a.out.expect[(long long)l * cap + j] = expect;
         }
 
-        int btype = -1;
+        stc(a.rays.p, cap, j, p);
+        int btype = -1, at_vertex = 0;
         V3 wgt = mk(1, 1, 1);
         if (depth + 1 < MCPT_MAX_DEPTH_DEV) {
             double u_rr, u_fresnel;
             uniform2(key, depth, 2u * nl, u_rr, u_fresnel);
             if (u_rr < MCPT_P_RR) {
-                Ray nr;
+                V3 nd = mk(0, 0, 0);
                 const V3 ks = ld3(m->ks);
                 if (m->Ni > 1) {
                     double n1, n2;
@@ -227,10 +227,11 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                     const double fresnel = rf0 + (1.0f - rf0) * pow5(1.0f - fabs(cos_in));
                     if (fresnel < u_fresnel) {
                         V3 direction;
-                        if (refract_dir(neg(dir), normal, n1 / n2, direction)) { nr.o = p; nr.d = direction; btype = RT_TRANSMISSION; }
+                        at_vertex = MCPT_BT_NO_OFFSET;
+                        if (refract_dir(neg(dir), normal, n1 / n2, direction)) { nd = direction; btype = RT_TRANSMISSION; }
                         else {
                             const V3 incoming = neg(dir);
-                            nr.o = p; nr.d = incoming - (normal * dot(incoming, normal)) * 2; btype = RT_SPECULAR;
+                            nd = incoming - (normal * dot(incoming, normal)) * 2; btype = RT_SPECULAR;
                         }
                     }
                 }
@@ -249,20 +250,18 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                         direction = brdf_sample(u_phi, u_theta, pn, RT_DIFFUSE, m->Ns);
                         btype = RT_DIFFUSE;
                     }
-                    nr.o = p + direction * 0.01; nr.d = direction;
+                    nd = direction;                                              // origin p + direction * 0.01
                 }
                 wgt = btype == RT_DIFFUSE ? kd : (btype == RT_SPECULAR ? ks : mk(1, 1, 1));
-                stc(a.rays.o + (long long)nl * 3 * cap, cap, j, nr.o);
-                stc(a.rays.d + (long long)nl * 3 * cap, cap, j, nr.d);
-                stc(a.out.bdir, cap, j, nr.d);
+                stc(a.out.bdir, cap, j, nd);
+                btype |= at_vertex;
                 ls.bounce++;
             }
         }
         a.out.id[j] = id;
         a.out.btype[j] = btype;
         stc(a.out.w, cap, j, wgt);
-        stc(a.out.T, cap, j, T);
-        stc(a.out.L, cap, j, L);
+        if (!FIRST) { stc(a.out.T, cap, j, T); stc(a.out.L, cap, j, L); }
         MCPT_LSTAMP(2)
     }
 #ifdef MCPT_TRACE_DIAG
@@ -288,10 +287,12 @@ struct WfRaySource {
         int l; long long j;
         split(q, l, j);
         // branch-free: the ray words are loaded whether or not the slot is in use, so nothing waits on the flag
-        const int flag = l == a.nl ? a.out.btype[j] : a.out.expect[(long long)l * a.cap + j];
-        r.o = ldc(a.rays.o + (long long)l * 3 * a.cap, a.cap, j);
-        r.d = ldc(a.rays.d + (long long)l * 3 * a.cap, a.cap, j);
-        return l == a.nl ? flag >= 0 : flag != -2;
+        const bool bounce = l == a.nl;
+        const int flag = bounce ? a.out.btype[j] : a.out.expect[(long long)l * a.cap + j];
+        const V3 p = ldc(a.rays.p, a.cap, j);
+        r.d = ldc(bounce ? a.out.bdir : a.rays.d + (long long)l * 3 * a.cap, a.cap, j);
+        r.o = (bounce && (flag & MCPT_BT_NO_OFFSET)) ? p : p + r.d * 0.01;
+        return bounce ? flag >= 0 : flag != -2;
     }
     __device__ __forceinline__ void store(long long q, bool ok, const Hit& h) const
     {
@@ -383,14 +384,16 @@ __global__ void __launch_bounds__(256) k_wf_finish(DScene S, WfArgs a)
     int* stack = lds_stack + threadIdx.x;
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
         const int id = a.out.id[j];
-        V3 T = ldc(a.out.T, cap, j), L = ldc(a.out.L, cap, j);
+        V3 T = mk(1, 1, 1), L = mk(0, 0, 0);
+        if (a.depth > 0) { T = ldc(a.out.T, cap, j); L = ldc(a.out.L, cap, j); }
+        const V3 p = ldc(a.rays.p, cap, j);
         V3 L_dir = mk(0, 0, 0);
         for (int l = 0; l < nl; l++) {
             const int expect = a.out.expect[(long long)l * cap + j];
             if (expect == -2) continue;
             Ray r;
-            r.o = ldc(a.rays.o + (long long)l * 3 * cap, cap, j);
             r.d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j);
+            r.o = p + r.d * 0.01;
             Hit h;
             const bool ok = trace_lane_fast(S, r, h, w, stack, 256);
             const bool vis = (ok ? S.tris[h.leaf].material : -1) == expect;
@@ -404,8 +407,8 @@ __global__ void __launch_bounds__(256) k_wf_finish(DScene S, WfArgs a)
         const int bt = a.out.btype[j];
         if (bt >= 0) {
             Ray r;
-            r.o = ldc(a.rays.o + (long long)nl * 3 * cap, cap, j);
-            r.d = ldc(a.rays.d + (long long)nl * 3 * cap, cap, j);
+            r.d = ldc(a.out.bdir, cap, j);
+            r.o = (bt & MCPT_BT_NO_OFFSET) ? p : p + r.d * 0.01;
             Hit h;
             if (trace_lane_fast(S, r, h, w, stack, 256)) {
                 const V3 wgt = ldc(a.out.w, cap, j);
@@ -414,7 +417,7 @@ __global__ void __launch_bounds__(256) k_wf_finish(DScene S, WfArgs a)
                 RngKey key;
                 key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
                 key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); key.sample = (uint32_t)(id % a.spp);
-                shade_path_from<true>(S, key, (uint32_t)a.depth + 1u, T, L, neg(r.d), bt, h, out, ls, stack, 256);
+                shade_path_from<true>(S, key, (uint32_t)a.depth + 1u, T, L, neg(r.d), bt & 7, h, out, ls, stack, 256);
             }
         }
         a.rad[(size_t)id * 3] = out[0]; a.rad[(size_t)id * 3 + 1] = out[1]; a.rad[(size_t)id * 3 + 2] = out[2];

@@ -17,24 +17,28 @@ namespace mcpt {
 
 struct WfState {            // one side of the double buffer; every array has `cap` entries per component
     int32_t* id;            // chunk-local sample id = (slot - first_slot) * spp + k
-    double* T;              // [3][cap] throughput at the vertex that was just shaded
-    double* L;              // [3][cap] radiance gathered before that vertex
+    double* T;              // [3][cap] throughput at the vertex that was just shaded   } not stored by the first pass:
+    double* L;              // [3][cap] radiance gathered before that vertex            } T = 1, L = 0 there
     // what shade(d) leaves for resolve(d):
     double* c;              // [nl][3][cap] direct-light contribution of light l if visible
     int32_t* expect;        // [nl][cap] material the shadow ray must hit to be visible; -2 = no shadow ray
     double* w;              // [3][cap] weight of the bounce (kd / ks / 1)
     double* bdir;           // [3][cap] direction of the bounce ray
-    int32_t* btype;         // [cap] ray_type of the bounce ray, -1 = none
+    int32_t* btype;         // [cap] ray_type of the bounce ray (| MCPT_BT_NO_OFFSET: it starts at the vertex itself), -1 = none
     // what trace(d) adds:
     int32_t* hit_mat;       // [nl][cap] material of the shadow ray's closest hit, -1 = miss
     int32_t* hit_leaf;      // [cap]     bounce ray: leaf or -1
     double* hit_p;          // [3][cap]  bounce ray: hit point
 };
 
-struct WfRays {             // written by logic(d), consumed by trace(d); slot (l, j), l = nl for the bounce ray
-    double* o;              // [nl+1][3][cap]
-    double* d;              // [nl+1][3][cap]
+// Rays of vertex d, written by logic(d), consumed by trace(d); slot (l, j), l = nl for the bounce ray.  All rays of a vertex
+// leave from p (+ 0.01 d, pathTracing.cpp:196,128; refraction and total reflection start at p itself, :97,:110), so p is
+// stored once and the origin is rebuilt where the ray is fetched; the bounce direction is WfState::bdir.
+struct WfRays {
+    double* p;              // [3][cap]     the shaded vertex
+    double* d;              // [nl][3][cap] shadow-ray directions
 };
+#define MCPT_BT_NO_OFFSET 8
 
 struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
     unsigned long long head;        // next unclaimed ray slot
