@@ -8,7 +8,10 @@
 
 namespace mcpt {
 
-constexpr int kFastMaxDepth = 32;          // inner levels; bounds the per-lane LDS stack
+#ifndef MCPT_FAST_STACK
+#define MCPT_FAST_STACK 32
+#endif
+constexpr int kFastMaxDepth = MCPT_FAST_STACK;          // inner levels; bounds the per-lane LDS stack
 constexpr int kFastMaxLeaf = 4;            // most triangles a leaf may hold (3 bits of the reference; bit 3 is a runtime flag)
 constexpr int kFastDefaultLeaf = 4;        // default leaf size (measured: 4 beats 1 and 2 on MI355X; inner steps cost more than leaf boxes)
 constexpr int32_t kFastEmpty = INT32_MIN;  // child reference of an absent child

@@ -10,8 +10,8 @@
 //     and by monotonicity no leaf below it is lost;
 //   * prunes by distance only beyond best_t + margin, margin = 1e-9 * scale / min|d_k| (>= 1e6 times the rounding
 //     error of t_k = (p.x-o.x)/d.x relative to the slab entry), and not at all when min|d_k| < 1e-6;
-//   * decides a triangle's own box from the same cheap interval when the outcome is certain (outside the 2^-48
-//     band) and with the reference's six true divisions otherwise;
+//   * decides a triangle's own box from reciprocals when the outcome is certain (outside the 2^-48 band, see
+//     own_box_hit) and with the reference's six true divisions otherwise;
 //   * runs the reference's triangle test and t_k computation unchanged.
 // Every other ray takes trace_closest().  The walk itself is in trace_persistent.hpp (per-lane stack: 32 entries in LDS).
 #pragma once
@@ -19,7 +19,9 @@
 
 namespace mcpt {
 
-#define MCPT_FAST_STACK 32
+#ifndef MCPT_FAST_STACK
+#define MCPT_FAST_STACK 32     /* per-lane traversal stack entries in LDS; accel_build.hpp bounds the hierarchy to it */
+#endif
 #define MCPT_FAST_EMPTY (-2147483647 - 1)
 
 struct Slab { double entry, exit; };
@@ -61,6 +63,48 @@ __device__ __forceinline__ bool box_hit_exact(const double lo[3], const double h
     if (txmax < 0 || tymax < 0 || tzmax < 0) return false;
     if (txmin <= 0 && tymin <= 0 && tzmin <= 0) return true;
     return dmax3(txmin, tymin, tzmin) <= dmin3(txmax, tymax, tzmax);
+}
+
+// The reference's box decision for a triangle's OWN box (bvh_intersect tests the leaf's box before the triangle,
+// pathTracing.cpp:334-345), from reciprocals wherever the outcome is certain.  The signs of (b-o)*(1/d) and (b-o)/d agree
+// (no underflow inside fast_path_ok's ranges), which settles "some tmax < 0" and "every tmin <= 0" exactly.  What remains is
+// dmax3(tmin) <= dmin3(tmax), i.e. tmin_a <= tmax_b for all axes a, b; for a == b it holds by construction (the reference
+// swaps), so only the six cross-axis pairs are compared -- this is what keeps a flat box (an axis-aligned triangle:
+// tmin == tmax on one axis) out of the six-division fallback.  Products and quotients differ by < 2^-50 relative; a pair is
+// decided from the products when they are more than 2^-48 apart.
+__device__ __forceinline__ bool own_box_hit(const DTri* __restrict__ tr, const Ray& r, const V3& rcp)
+{
+    double lo[3], hi[3];
+    lo[0] = dmin3(tr->v1[0], tr->v2[0], tr->v3[0]); hi[0] = dmax3(tr->v1[0], tr->v2[0], tr->v3[0]);
+    lo[1] = dmin3(tr->v1[1], tr->v2[1], tr->v3[1]); hi[1] = dmax3(tr->v1[1], tr->v2[1], tr->v3[1]);
+    lo[2] = dmin3(tr->v1[2], tr->v2[2], tr->v3[2]); hi[2] = dmax3(tr->v1[2], tr->v2[2], tr->v3[2]);
+    const double ax = (lo[0] - r.o.x) * rcp.x, bx = (hi[0] - r.o.x) * rcp.x;
+    const double ay = (lo[1] - r.o.y) * rcp.y, by = (hi[1] - r.o.y) * rcp.y;
+    const double az = (lo[2] - r.o.z) * rcp.z, bz = (hi[2] - r.o.z) * rcp.z;
+    const double nx = fmin(ax, bx), fx = fmax(ax, bx);
+    const double ny = fmin(ay, by), fy = fmax(ay, by);
+    const double nz = fmin(az, bz), fz = fmax(az, bz);
+    if (fx < 0.0 || fy < 0.0 || fz < 0.0) return false;
+    if (nx <= 0.0 && ny <= 0.0 && nz <= 0.0) return true;
+    const double ex = fmin(fy, fz), ey = fmin(fx, fz), ez = fmin(fx, fy);          // exits of the other two axes, all >= 0
+    if (nx + fabs(nx) * 0x1p-48 <= ex && ny + fabs(ny) * 0x1p-48 <= ey && nz + fabs(nz) * 0x1p-48 <= ez) return true;
+    if (nx > ex + ex * 0x1p-48 || ny > ey + ey * 0x1p-48 || nz > ez + ez * 0x1p-48) return false;
+    return box_hit_exact(lo, hi, r);
+}
+
+// A triangle's test passed at p.  Does it replace the best candidate?  The remaining conditions of the reference are a
+// conjunction of pure tests (own box, t > 0, (t, k) lexicographically below the best), evaluated cheapest first:
+// sign and rank of t from the reciprocal where that is certain, then the box, then t itself with the reference's division.
+__device__ __forceinline__ bool better_candidate(const DTri* __restrict__ tr, const Ray& r, const V3& rcp, const V3& p, bool found,
+                                                 const Hit& best, double& t, int& k)
+{
+    const double ta = (p.x - r.o.x) * rcp.x;                // same sign as t, within 2^-50 of it
+    if (!(ta > 0.0)) return false;
+    if (found && ta > best.t + best.t * 0x1p-48) return false;
+    if (!own_box_hit(tr, r, rcp)) return false;
+    t = (p.x - r.o.x) / r.d.x;                              // pathTracing.cpp:347
+    k = tr->leaf;
+    return t > 0 && (!found || t < best.t || (t == best.t && k < best.leaf));
 }
 
 // Rays the fast walk may take.  fp64 side (exact decisions at the leaves): no under/overflow in (b-o)*(1/d);
@@ -195,22 +239,8 @@ __device__ __forceinline__ bool trace_lane_fast(const DScene& S, const Ray& r, H
             V3 p;
             w.tris++;
             if (!tri_hit(tr, r, p)) continue;
-            double lo[3], hi[3];
-            lo[0] = dmin3(tr->v1[0], tr->v2[0], tr->v3[0]); hi[0] = dmax3(tr->v1[0], tr->v2[0], tr->v3[0]);
-            lo[1] = dmin3(tr->v1[1], tr->v2[1], tr->v3[1]); hi[1] = dmax3(tr->v1[1], tr->v2[1], tr->v3[1]);
-            lo[2] = dmin3(tr->v1[2], tr->v2[2], tr->v3[2]); hi[2] = dmax3(tr->v1[2], tr->v2[2], tr->v3[2]);
-            const Slab s = slab_interval(lo, hi, r.o, rcp);
-            bool pass = false;
-            if (!(s.exit < 0.0)) {
-                if (s.entry <= 0.0) pass = true;
-                else if (s.entry + s.entry * 0x1p-48 <= s.exit) pass = true;
-                else if (s.entry > s.exit + s.exit * 0x1p-48) pass = false;
-                else pass = box_hit_exact(lo, hi, r);
-            }
-            if (!pass) continue;
-            const double t = (p.x - r.o.x) / r.d.x;
-            const int k = tr->leaf;
-            if (t > 0 && (!found || t < best.t || (t == best.t && k < best.leaf))) {
+            double t; int k;
+            if (better_candidate(tr, r, rcp, p, found, best, t, k)) {
                 found = true; best.leaf = k; best.t = t; best.p = p;
                 limit = t + margin;
                 limit_f = __double2float_ru(limit);

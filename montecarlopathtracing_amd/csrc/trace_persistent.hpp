@@ -185,30 +185,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                 tri_i++;
                 // Candidate = own box passes AND triangle test passes AND t > 0 -- a conjunction of pure tests, so the
                 // order of evaluation is free: the triangle test goes first (about one visited triangle in five passes it),
-                // the reference's box decision is made only for those.
+                // the rest (better_candidate) is evaluated only for those.
                 V3 p;
                 w.tris++;
                 if (tri_hit(tr, r, p)) {
-                    double lo[3], hi[3];
-                    lo[0] = dmin3(tr->v1[0], tr->v2[0], tr->v3[0]); hi[0] = dmax3(tr->v1[0], tr->v2[0], tr->v3[0]);
-                    lo[1] = dmin3(tr->v1[1], tr->v2[1], tr->v3[1]); hi[1] = dmax3(tr->v1[1], tr->v2[1], tr->v3[1]);
-                    lo[2] = dmin3(tr->v1[2], tr->v2[2], tr->v3[2]); hi[2] = dmax3(tr->v1[2], tr->v2[2], tr->v3[2]);
-                    const Slab s = slab_interval(lo, hi, r.o, rcp);
-                    bool pass = false;
-                    if (!(s.exit < 0.0)) {
-                        if (s.entry <= 0.0) pass = true;
-                        else if (s.entry + s.entry * 0x1p-48 <= s.exit) pass = true;
-                        else if (s.entry > s.exit + s.exit * 0x1p-48) pass = false;
-                        else pass = box_hit_exact(lo, hi, r);
-                    }
-                    if (pass) {
-                        const double t = (p.x - r.o.x) / r.d.x;
-                        const int k = tr->leaf;
-                        if (t > 0 && (!found || t < best.t || (t == best.t && k < best.leaf))) {
-                            found = true; best.leaf = k; best.t = t; best.p = p;
-                            limit = t + margin;
-                            limit_f = __double2float_ru(limit);
-                        }
+                    double t; int k;
+                    if (better_candidate(tr, r, rcp, p, found, best, t, k)) {
+                        found = true; best.leaf = k; best.t = t; best.p = p;
+                        limit = t + margin;
+                        limit_f = __double2float_ru(limit);
                     }
                 }
                 if (tri_i >= tri_end) {                  // leaf done: pop

@@ -316,7 +316,10 @@ __device__ __forceinline__ long long wf_chunk(long long total)
     return c < 64 ? 64 : (c > 2048 ? 2048 : c);
 }
 
-__global__ void __launch_bounds__(256, 3) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap)
+#ifndef MCPT_TRACE_WAVES
+#define MCPT_TRACE_WAVES 3   /* waves per SIMD: 168 VGPRs, 45 KB of LDS per block */
+#endif
+__global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap)
 {
     const long long n_paths = a.counts->n_next;
     if (n_paths == 0) return;
