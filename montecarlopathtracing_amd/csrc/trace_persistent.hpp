@@ -104,6 +104,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         unsigned long long idle = __ballot(state == ST_IDLE);
         const bool supply = lds_taken < lds_count || reg_count > 0;
         if (idle && supply && (__popcll(idle) >= MCPT_REFILL_LANES || idle == ~0ull)) {
+            // results of the rays that ended since the last refill go out in one batch: a store between two node loads
+            // would put its acknowledge time on the walking lanes' critical path (loads and stores share one counter)
+            if (state == ST_IDLE && slot >= 0) { src.store(slot, found, best); slot = -1; }
             for (;;) {
                 idle = __ballot(state == ST_IDLE);
                 if (!idle) break;
@@ -175,7 +178,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                 int nxt = h.ref[0];
                 if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = stack[sp * stride]; }
                 if (nxt >= 0) cur = nxt;
-                else if (nxt == MCPT_FAST_EMPTY) { src.store(slot, found, best); state = ST_IDLE; }
+                else if (nxt == MCPT_FAST_EMPTY) state = ST_IDLE;                 // result stored at the next refill
                 else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; state = ST_TRI; }
             }
         } else {
@@ -202,11 +205,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                         const int nxt = stack[sp * stride];
                         if (nxt >= 0) { cur = nxt; state = ST_INNER; }
                         else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
-                    } else { src.store(slot, found, best); state = ST_IDLE; }
+                    } else state = ST_IDLE;
                 }
             }
         }
     }
+    if (slot >= 0) src.store(slot, found, best);
 }
 
 // second pass: the deferred rays, one lane each, reference-shaped walk.  If more rays were deferred than the side list
