@@ -93,31 +93,31 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                 ls.samples = 1;
             } else {
                 // ---- resolve vertex depth-1 (pathTracing.cpp:213-231, 244-261)
+                // Every word of the path is requested before any is looked at (what a dead path or an unused shadow slot
+                // holds is stale but harmless): one memory latency per pass instead of a chain of three.
                 id = a.in.id[i];
+                const int bt = a.in.btype[i];
+                const int hl = a.in.hit_leaf[i];
                 if (depth > 1) { T = ldc(a.in.T, cap, i); L = ldc(a.in.L, cap, i); }
+                const V3 wgt = ldc(a.in.w, cap, i);
+                const V3 hp = ldc(a.in.hit_p, cap, i);
+                const V3 bd = ldc(a.in.bdir, cap, i);
                 V3 L_dir = mk(0, 0, 0);
                 for (int l = 0; l < nl; l++) {
                     const int expect = a.in.expect[(long long)l * cap + i];
-                    if (expect == -2) continue;
+                    const int hm = a.in.hit_mat[(long long)l * cap + i];
                     const V3 c = ldc(a.in.c + (long long)l * 3 * cap, cap, i);
-                    const bool vis = a.in.hit_mat[(long long)l * cap + i] == expect;
+                    if (expect == -2) continue;
+                    const bool vis = hm == expect;
                     L_dir.x += vis ? c.x : c.x * 0.0;
                     L_dir.y += vis ? c.y : c.y * 0.0;
                     L_dir.z += vis ? c.z : c.z * 0.0;
                 }
                 L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
-                const int bt = a.in.btype[i];
-                have_vertex = false;
-                if (bt >= 0) {
-                    const int hl = a.in.hit_leaf[i];
-                    if (hl >= 0) {
-                        const V3 wgt = ldc(a.in.w, cap, i);
-                        T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
-                        leaf = hl; p = ldc(a.in.hit_p, cap, i);
-                        dir = neg(ldc(a.in.bdir, cap, i));
-                        in_type = bt & 7;
-                        have_vertex = true;
-                    }
+                have_vertex = bt >= 0 && hl >= 0;
+                if (have_vertex) {
+                    T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
+                    leaf = hl; p = hp; dir = neg(bd); in_type = bt & 7;
                 }
             }
             if (have_vertex) {
