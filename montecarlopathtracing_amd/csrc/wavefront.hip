@@ -27,7 +27,7 @@ __device__ __forceinline__ void stc(double* __restrict__ a, long long cap, long 
 
 size_t wf_bytes_per_path(int nl)
 {
-    const size_t state = 4 + (6 + 3 * nl + 6) * 8 + nl * 4 + 4 + nl * 4 + 4 + 3 * 8;   // WfState
+    const size_t state = 4 + (6 + 3 * nl + (nl == 1 ? 3 : 6)) * 8 + nl * 4 + 4 + nl * 4 + 4 + 3 * 8;   // WfState (no w with one light)
     const size_t rays = (1 + nl) * 3 * 8;                                            // WfRays
     return 2 * state + rays;
 }
@@ -41,7 +41,7 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfSta
         s.id = static_cast<int32_t*>(take(cap * 4));
         s.T = static_cast<double*>(take(cap * 24)); s.L = static_cast<double*>(take(cap * 24));
         s.c = static_cast<double*>(take(size_t(cap) * 24 * nl)); s.expect = static_cast<int32_t*>(take(size_t(cap) * 4 * nl));
-        s.w = static_cast<double*>(take(cap * 24)); s.bdir = static_cast<double*>(take(cap * 24));
+        s.w = nl == 1 ? nullptr : static_cast<double*>(take(cap * 24)); s.bdir = static_cast<double*>(take(cap * 24));
         s.btype = static_cast<int32_t*>(take(cap * 4));
         s.hit_mat = static_cast<int32_t*>(take(size_t(cap) * 4 * nl)); s.hit_leaf = static_cast<int32_t*>(take(cap * 4));
         s.hit_p = static_cast<double*>(take(cap * 24));
@@ -61,6 +61,9 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
     __shared__ unsigned int block_base;
     const long long cap = a.cap;
     const int nl = a.nl;
+    // One light (the usual scene): T * c and T * w / P_RR are formed when the vertex is shaded instead of when it is resolved --
+    // the same products, one pass earlier -- so the bounce weight never goes through memory.
+    const bool folded = nl == 1;
     const uint32_t depth = (uint32_t)a.depth;           // depth of the vertex shaded in this pass
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     LaneStats ls;
@@ -98,8 +101,11 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                 id = a.in.id[i];
                 const int bt = a.in.btype[i];
                 const int hl = a.in.hit_leaf[i];
-                if (depth > 1) { T = ldc(a.in.T, cap, i); L = ldc(a.in.L, cap, i); }
-                const V3 wgt = ldc(a.in.w, cap, i);
+                // folded (one light): in.T already is the throughput after the bounce and in.c is T * c (see the stores below)
+                if (depth > 1 || folded) T = ldc(a.in.T, cap, i);
+                if (depth > 1) L = ldc(a.in.L, cap, i);
+                V3 wgt = mk(1, 1, 1);
+                if (!folded) wgt = ldc(a.in.w, cap, i);
                 const V3 hp = ldc(a.in.hit_p, cap, i);
                 const V3 bd = ldc(a.in.bdir, cap, i);
                 V3 L_dir = mk(0, 0, 0);
@@ -113,12 +119,14 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                     L_dir.y += vis ? c.y : c.y * 0.0;
                     L_dir.z += vis ? c.z : c.z * 0.0;
                 }
-                L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
                 have_vertex = bt >= 0 && hl >= 0;
-                if (have_vertex) {
-                    T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
-                    leaf = hl; p = hp; dir = neg(bd); in_type = bt & 7;
+                if (folded) {
+                    L = L + L_dir;
+                } else {
+                    L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
+                    if (have_vertex) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
                 }
+                if (have_vertex) { leaf = hl; p = hp; dir = neg(bd); in_type = bt & 7; }
             }
             if (have_vertex) {
                 ls.shades++;
@@ -200,7 +208,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                 const double dist = (1.0 < dd) ? dd : 1.0;
                 const V3 intensity = ((ld3(lt->radiance) * cos_theta) * cos_theta_hat) * (frcp(sqr(dist)) * lt->total_area);
                 const V3 c = mk(kd.x * intensity.x * kd_dots * MCPT_INV_PI, kd.y * intensity.y * kd_dots * MCPT_INV_PI, kd.z * intensity.z * kd_dots * MCPT_INV_PI);
-                stc(a.out.c + (long long)l * 3 * cap, cap, j, c);
+                stc(a.out.c + (long long)l * 3 * cap, cap, j, folded ? mk(T.x * c.x, T.y * c.y, T.z * c.z) : c);
                 stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);       // origin p + direction * 0.01: WfRaySource
                 expect = sample_mat;
                 ls.shadow++;
@@ -208,7 +216,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             a.out.expect[(long long)l * cap + j] = expect;
         }
 
-        stc(a.rays.p, cap, j, p);
+        if (!FIRST) stc(a.rays.p, cap, j, p);            // first pass: the pixel's primary hit, read from a.hits where needed
         int btype = -1, at_vertex = 0;
         V3 wgt = mk(1, 1, 1);
         if (depth + 1 < MCPT_MAX_DEPTH_DEV) {
@@ -260,8 +268,9 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         }
         a.out.id[j] = id;
         a.out.btype[j] = btype;
-        stc(a.out.w, cap, j, wgt);
-        if (!FIRST) { stc(a.out.T, cap, j, T); stc(a.out.L, cap, j, L); }
+        if (folded) stc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
+        else { stc(a.out.w, cap, j, wgt); if (!FIRST) stc(a.out.T, cap, j, T); }
+        if (!FIRST) stc(a.out.L, cap, j, L);
         MCPT_LSTAMP(2)
     }
 #ifdef MCPT_TRACE_DIAG
@@ -282,6 +291,15 @@ struct WfRaySource {
         l = 0; j = q;
         while (j >= n_paths) { j -= n_paths; l++; }
     }
+    // the vertex the rays of path j leave from: after the first pass every sample of a pixel still sits on its primary hit
+    __device__ __forceinline__ V3 vertex(long long j) const
+    {
+        if (a.depth == 0) {
+            const PrimaryHit* ph = a.hits + (a.first_slot + a.out.id[j] / a.spp);
+            return mk(ph->p[0], ph->p[1], ph->p[2]);
+        }
+        return ldc(a.rays.p, a.cap, j);
+    }
     __device__ __forceinline__ bool fetch(long long q, Ray& r) const
     {
         int l; long long j;
@@ -289,7 +307,7 @@ struct WfRaySource {
         // branch-free: the ray words are loaded whether or not the slot is in use, so nothing waits on the flag
         const bool bounce = l == a.nl;
         const int flag = bounce ? a.out.btype[j] : a.out.expect[(long long)l * a.cap + j];
-        const V3 p = ldc(a.rays.p, a.cap, j);
+        const V3 p = vertex(j);
         r.d = ldc(bounce ? a.out.bdir : a.rays.d + (long long)l * 3 * a.cap, a.cap, j);
         r.o = (bounce && (flag & MCPT_BT_NO_OFFSET)) ? p : p + r.d * 0.01;
         return bounce ? flag >= 0 : flag != -2;
@@ -387,9 +405,12 @@ __global__ void __launch_bounds__(256) k_wf_finish(DScene S, WfArgs a)
     int* stack = lds_stack + threadIdx.x;
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
         const int id = a.out.id[j];
+        const bool folded = nl == 1;                     // see k_wf_logic
         V3 T = mk(1, 1, 1), L = mk(0, 0, 0);
-        if (a.depth > 0) { T = ldc(a.out.T, cap, j); L = ldc(a.out.L, cap, j); }
-        const V3 p = ldc(a.rays.p, cap, j);
+        if (a.depth > 0 || folded) T = ldc(a.out.T, cap, j);
+        if (a.depth > 0) L = ldc(a.out.L, cap, j);
+        WfRaySource src; src.a = a; src.n_paths = n;
+        const V3 p = src.vertex(j);
         V3 L_dir = mk(0, 0, 0);
         for (int l = 0; l < nl; l++) {
             const int expect = a.out.expect[(long long)l * cap + j];
@@ -405,7 +426,7 @@ __global__ void __launch_bounds__(256) k_wf_finish(DScene S, WfArgs a)
             L_dir.y += vis ? c.y : c.y * 0.0;
             L_dir.z += vis ? c.z : c.z * 0.0;
         }
-        L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
+        L = folded ? L + L_dir : L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
         double out[3] = {L.x, L.y, L.z};
         const int bt = a.out.btype[j];
         if (bt >= 0) {
@@ -414,8 +435,10 @@ __global__ void __launch_bounds__(256) k_wf_finish(DScene S, WfArgs a)
             r.o = (bt & MCPT_BT_NO_OFFSET) ? p : p + r.d * 0.01;
             Hit h;
             if (trace_lane_fast(S, r, h, w, stack, 256)) {
-                const V3 wgt = ldc(a.out.w, cap, j);
-                T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
+                if (!folded) {
+                    const V3 wgt = ldc(a.out.w, cap, j);
+                    T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
+                }
                 const int slot = a.first_slot + id / a.spp;
                 RngKey key;
                 key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
@@ -511,7 +534,8 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
     static int grid = 0;
     if (!grid) grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace));
     // a wave that starts pays one atomic on the queue head and a few on the counters: give every block >= 2048 rays
-    const long long blocks_needed = (total + 2047) / 2048;
+    static const long long rays_per_block = [] { const char* e = std::getenv("MCPT_TRACE_BLOCK_RAYS"); const long long v = e ? std::atoll(e) : 0; return v >= 256 ? v : 2048; }();
+    const long long blocks_needed = (total + rays_per_block - 1) / rays_per_block;
     const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
     hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);

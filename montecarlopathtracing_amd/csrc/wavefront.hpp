@@ -17,12 +17,13 @@ namespace mcpt {
 
 struct WfState {            // one side of the double buffer; every array has `cap` entries per component
     int32_t* id;            // chunk-local sample id = (slot - first_slot) * spp + k
-    double* T;              // [3][cap] throughput at the vertex that was just shaded   } not stored by the first pass:
-    double* L;              // [3][cap] radiance gathered before that vertex            } T = 1, L = 0 there
+    double* T;              // [3][cap] throughput at the vertex that was just shaded (one light: after its bounce, and
+                            //          c = T * c); several lights: not stored by the first pass (T = 1)
+    double* L;              // [3][cap] radiance gathered before that vertex; not stored by the first pass (L = 0)
     // what shade(d) leaves for resolve(d):
     double* c;              // [nl][3][cap] direct-light contribution of light l if visible
     int32_t* expect;        // [nl][cap] material the shadow ray must hit to be visible; -2 = no shadow ray
-    double* w;              // [3][cap] weight of the bounce (kd / ks / 1)
+    double* w;              // [3][cap] weight of the bounce (kd / ks / 1); with one light it is folded into T and c instead
     double* bdir;           // [3][cap] direction of the bounce ray
     int32_t* btype;         // [cap] ray_type of the bounce ray (| MCPT_BT_NO_OFFSET: it starts at the vertex itself), -1 = none
     // what trace(d) adds:
