@@ -83,7 +83,7 @@ struct mcpt_device {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t sample_budget_bytes = size_t(4) << 30;   // megakernel path: radiance staging buffer per chunk
     // wavefront workspace
-    size_t wf_budget_bytes = size_t(40) << 30;      // path state + rays (MCPT_WORKSPACE_GB overrides)
+    size_t wf_budget_bytes = 0;                     // path state + rays; 0 = half of the free HBM (MCPT_WORKSPACE_GB overrides)
     void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
     int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
     WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
@@ -767,7 +767,15 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
     const size_t bpp = wf_bytes_per_path(nl);
     // chunk: as many pixels as the workspace budget holds paths for (every pixel may hit)
     const size_t overhead = 64 * 1024;
-    int64_t cap = int64_t((d->wf_budget_bytes - overhead) / (bpp + 24));      // + 24 B radiance per sample
+    // Fewer, larger chunks are cheaper (every chunk ends in a tail of small launches): by default a chunk may use half of
+    // the HBM that is free, which holds a whole 1280x720 SPP-256 frame (83 GB) on a 288-GB device.
+    size_t budget = d->wf_budget_bytes;
+    if (!budget) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        budget = std::max<size_t>((free_b + d->wf_ws_bytes + d->rad_cap) / 2, size_t(1) << 30);
+    }
+    int64_t cap = int64_t((budget - overhead) / (bpp + 24));      // + 24 B radiance per sample
     cap = std::min<int64_t>(cap, npx * int64_t(spp));
     cap = std::min<int64_t>(cap, (int64_t(1) << 31) - 4096);                 // 32-bit compaction counter / sample ids
     int64_t chunk_slots = std::max<int64_t>(cap / spp, 1);

@@ -183,6 +183,26 @@ def test_partition_independent(pair, mcpt):
     assert np.array_equal(_bits(full), _bits(parts))
 
 
+def test_chunked_frame_equals_single_chunk(mcpt, monkeypatch):
+    """By default the path state of a whole frame sits in HBM at once; with a 16-MB workspace the same frame takes dozens of
+    chunks (and the small tail launches of each).  Same samples, same arithmetic: the same bits."""
+    monkeypatch.setenv("MCPT_FINISH_PATHS", "500")        # keep the wavefront iterations going in the small chunks too
+    sc = mcpt.Scene(SCENES, "cornell-box", width=160, height=120)
+    one = mcpt.Device(sc, 0)
+    st1 = mcpt.Stats()
+    a = one.generateImg(12, seed=4, stats=st1)
+    one.close()
+    monkeypatch.setenv("MCPT_WORKSPACE_GB", "0.016")
+    many = mcpt.Device(sc, 0)
+    st2 = mcpt.Stats()
+    b = many.generateImg(12, seed=4, stats=st2)
+    many.close()
+    sc.close()
+    assert st2.launches > 2 * st1.launches
+    assert np.array_equal(_bits(a), _bits(b))
+    assert (st1.rays_shadow + st1.shadow_skipped, st1.rays_bounce, st1.shade_calls) == (st2.rays_shadow + st2.shadow_skipped, st2.rays_bounce, st2.shade_calls)
+
+
 def _blocks(img8, b):
     h, w, _ = img8.shape
     hh, ww = (h // b) * b, (w // b) * b
