@@ -802,6 +802,7 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
     if (!wf_carve(d->wf_ws, d->wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
     a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = d->hit_slots; a.hits = d->hits;
     a.dirs = d->dirs; a.rad = d->rad; a.counts = d->wf_counts; a.ctr = d->ctr; a.tris = d->tris;
+    a.finish_below = fast ? unsigned(std::min<long long>(std::max<long long>(d->finish_threshold, 0), 1ll << 30)) : 0u;
     // Iterations are enqueued without waiting for their counts: every kernel reads its input count from the device slot the
     // previous one wrote.  The host looks at a count only every few iterations (to stop, and to size the next grids).
     size_t ev_used = 0;
@@ -823,7 +824,6 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
         HIP_TRY(hipGetLastError());
         long long n_upper = (long long)n_slots * spp;        // upper bound of the live paths, refined at every look
         double n_grid = double(n_upper);                     // grid-sizing estimate between looks (kernels stride, any grid is correct)
-        bool exact_count = false;                            // n_upper was read from the device after the last logic pass
         a.first_slot = int(first);
         a.in = A; a.out = B;
         for (int depth = 0; depth < MCPT_MAX_DEPTH && n_upper > 0; depth++) {
@@ -833,12 +833,10 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
             const long long n_launch = std::max<long long>(1, (long long)n_grid);
             launch_wf_logic(d->ds, a, n_launch, depth == 0, st);
             HIP_TRY(hipGetLastError());
-            if (fast && exact_count && n_upper <= d->finish_threshold) {
-                // few paths left: one lane per path runs them to the end (wavefront.hip: k_wf_finish)
-                launch_wf_finish(d->ds, a, n_upper, st);
+            if (a.finish_below) {
+                // few paths left (decided on the device from this pass's count): one lane per path runs them to the end
+                launch_wf_finish(d->ds, a, std::min<long long>(n_launch, (long long)a.finish_below), st);
                 HIP_TRY(hipGetLastError());
-                n_upper = 0;
-                break;
             }
             std::pair<hipEvent_t, hipEvent_t>* pr = nullptr;
             if (stats) { if ((rc = next_pair(pr))) return rc; HIP_TRY(hipEventRecord(pr->first, st)); }
@@ -851,10 +849,9 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
                 unsigned int n_now = 0;
                 HIP_TRY(hipMemcpyAsync(&n_now, &d->wf_counts[depth + 1].n_next, sizeof n_now, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                n_upper = n_now;
+                n_upper = n_now <= a.finish_below ? 0 : n_now;
                 n_grid = double(n_now);
-                exact_count = true;
-            } else { n_grid *= 0.75; exact_count = false; }   // paths die at >= 40 % per bounce (Russian roulette 0.6)
+            } else n_grid *= 0.75;   // paths die at >= 40 % per bounce (Russian roulette 0.6)
         }
         // paths still alive at the depth cap cannot exist: logic(MAX_DEPTH-1) emits no bounce ray; a last logic pass resolves them
         if (n_upper > 0) {

@@ -57,6 +57,7 @@ template <bool FIRST>
 __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a)
 {
     const long long n_prev = (long long)a.counts_in->n_next * a.count_mul;
+    if (!FIRST && n_prev <= (long long)a.finish_below) return;         // those paths went to k_wf_finish
     __shared__ unsigned int wave_tot[4];
     __shared__ unsigned int block_base;
     const long long cap = a.cap;
@@ -326,22 +327,22 @@ struct WfRaySource {
 };
 
 // persistent fast walk
-__device__ __forceinline__ long long wf_chunk(long long total)
+__device__ __forceinline__ long long wf_chunk(long long total, int min_chunk)
 {
     const long long waves = (long long)gridDim.x * 4;
     long long c = total / (waves * 4);
     c = (c / 64) * 64;
-    return c < 64 ? 64 : (c > 2048 ? 2048 : c);
+    return c < min_chunk ? min_chunk : (c > 2048 ? 2048 : c);
 }
 
 #ifndef MCPT_TRACE_WAVES
 #define MCPT_TRACE_WAVES 3   /* waves per SIMD: 168 VGPRs, 45 KB of LDS per block */
 #endif
-__global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap)
+__global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, int min_chunk)
 {
     const long long n_paths = a.counts->n_next;
-    if (n_paths == 0) return;
-    const long long chunk = wf_chunk(n_paths * (a.nl + 1));
+    if (n_paths <= (long long)a.finish_below) return;                  // nothing left, or k_wf_finish has taken the paths
+    const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk);
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
     WfRaySource src; src.a = a; src.n_paths = n_paths;
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, Wf
     ls.nodes = w.nodes; ls.tris = w.tris;
     if (a.ctr) {        // the dominant kernel's own work, for its roofline
         const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&a.ctr->trace_nodes, tn); atomicAdd(&a.ctr->trace_tris, tt); atomicAdd(&a.ctr->trace_rays, tr); }
+        if ((threadIdx.x & 63) == 0 && tr) { atomicAdd(&a.ctr->trace_nodes, tn); atomicAdd(&a.ctr->trace_tris, tt); atomicAdd(&a.ctr->trace_rays, tr); }
     }
 #ifdef MCPT_TRACE_DIAG
     if ((threadIdx.x & 63) == 0 && a.ctr) for (int i = 0; i < 8; i++) atomicAdd(&a.ctr->pad[i], w.diag[i]);
@@ -362,7 +363,7 @@ __global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, Wf
 __global__ void __launch_bounds__(256) k_wf_trace_slow(DScene S, WfArgs a, const TraceQueue* queue, const long long* slow_list, unsigned int slow_cap)
 {
     const long long n_paths = a.counts->n_next;
-    if (n_paths == 0 || queue->slow_count == 0) return;
+    if (n_paths <= (long long)a.finish_below || queue->slow_count == 0) return;
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
@@ -394,10 +395,11 @@ __global__ void __launch_bounds__(256) k_wf_trace_reference(DScene S, WfArgs a)
 // When only a few thousand paths are left, a launch pair per bounce costs more than the paths: every remaining path is run
 // to its end by one lane.  Input = the state logic(depth) has just written (its rays not yet traced): trace them, resolve the
 // vertex exactly as the next logic pass would, then continue with the shared path loop (shade_path_from).
-__global__ void __launch_bounds__(256) k_wf_finish(DScene S, WfArgs a)
+__global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
 {
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     const long long n = a.counts->n_next;
+    if (n > (long long)a.finish_below) return;                         // still wavefront work
     const long long cap = a.cap;
     const int nl = a.nl;
     LaneStats ls;
@@ -538,7 +540,10 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
     const long long blocks_needed = (total + rays_per_block - 1) / rays_per_block;
     const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
+    // every claim is an atomic on one word (~88 per microsecond on this chip): below this many rays per claim the queue head,
+    // not the walk, bounds a launch of a million rays
+    static const int min_chunk = [] { const char* e = std::getenv("MCPT_TRACE_MIN_CHUNK"); const int v = e ? std::atoi(e) : 0; return v >= 64 ? v / 64 * 64 : 256; }();
+    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, min_chunk);
     hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 64 ? g : 64), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
 }
 

@@ -70,6 +70,9 @@ struct WfArgs {
     unsigned int count_mul;     // input paths = counts_in->n_next * count_mul (spp for the first pass, 1 afterwards)
     DCounters* ctr;
     const DTri* tris;           // S.tris (material of a shadow ray's hit)
+    // Hand-over to the finishing kernel, decided on the device: when logic(d) leaves at most this many paths, k_wf_finish
+    // (launched after every logic pass) runs them to their end and trace(d), logic(d+1), ... find nothing to do.  0 = never.
+    unsigned int finish_below;
 };
 
 size_t wf_bytes_per_path(int nl);
