@@ -6,7 +6,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmcpt.so")
+LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(CSRC, "libmcpt.so")     # MCPT_LIB: a differently tuned build (tools/)
 
 
 class McptError(RuntimeError):

@@ -65,6 +65,11 @@ __device__ __forceinline__ bool box_hit_exact(const double lo[3], const double h
     return dmax3(txmin, tymin, tzmin) <= dmin3(txmax, tymax, tzmax);
 }
 
+// v_min_f64 / v_max_f64 as they are (the compiler's fmin/fmax first quiets each operand with an extra instruction; the operands
+// here are finite)
+__device__ __forceinline__ double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // The reference's box decision for a triangle's OWN box (bvh_intersect tests the leaf's box before the triangle,
 // pathTracing.cpp:334-345), from reciprocals wherever the outcome is certain.  The signs of (b-o)*(1/d) and (b-o)/d agree
 // (no underflow inside fast_path_ok's ranges), which settles "some tmax < 0" and "every tmin <= 0" exactly.  What remains is
@@ -74,19 +79,21 @@ __device__ __forceinline__ bool box_hit_exact(const double lo[3], const double h
 // decided from the products when they are more than 2^-48 apart.
 __device__ __forceinline__ bool own_box_hit(const DTri* __restrict__ tr, const Ray& r, const V3& rcp)
 {
+    // the leaf's box (BVH.cpp:87-97); vertices are finite (fast_path_ok's scene condition), so min/max instructions give the
+    // reference's if-chain values up to the sign of a zero, which no comparison below can see
     double lo[3], hi[3];
-    lo[0] = dmin3(tr->v1[0], tr->v2[0], tr->v3[0]); hi[0] = dmax3(tr->v1[0], tr->v2[0], tr->v3[0]);
-    lo[1] = dmin3(tr->v1[1], tr->v2[1], tr->v3[1]); hi[1] = dmax3(tr->v1[1], tr->v2[1], tr->v3[1]);
-    lo[2] = dmin3(tr->v1[2], tr->v2[2], tr->v3[2]); hi[2] = dmax3(tr->v1[2], tr->v2[2], tr->v3[2]);
+    lo[0] = vmin(vmin(tr->v1[0], tr->v2[0]), tr->v3[0]); hi[0] = vmax(vmax(tr->v1[0], tr->v2[0]), tr->v3[0]);
+    lo[1] = vmin(vmin(tr->v1[1], tr->v2[1]), tr->v3[1]); hi[1] = vmax(vmax(tr->v1[1], tr->v2[1]), tr->v3[1]);
+    lo[2] = vmin(vmin(tr->v1[2], tr->v2[2]), tr->v3[2]); hi[2] = vmax(vmax(tr->v1[2], tr->v2[2]), tr->v3[2]);
     const double ax = (lo[0] - r.o.x) * rcp.x, bx = (hi[0] - r.o.x) * rcp.x;
     const double ay = (lo[1] - r.o.y) * rcp.y, by = (hi[1] - r.o.y) * rcp.y;
     const double az = (lo[2] - r.o.z) * rcp.z, bz = (hi[2] - r.o.z) * rcp.z;
-    const double nx = fmin(ax, bx), fx = fmax(ax, bx);
-    const double ny = fmin(ay, by), fy = fmax(ay, by);
-    const double nz = fmin(az, bz), fz = fmax(az, bz);
+    const double nx = vmin(ax, bx), fx = vmax(ax, bx);
+    const double ny = vmin(ay, by), fy = vmax(ay, by);
+    const double nz = vmin(az, bz), fz = vmax(az, bz);
     if (fx < 0.0 || fy < 0.0 || fz < 0.0) return false;
     if (nx <= 0.0 && ny <= 0.0 && nz <= 0.0) return true;
-    const double ex = fmin(fy, fz), ey = fmin(fx, fz), ez = fmin(fx, fy);          // exits of the other two axes, all >= 0
+    const double ex = vmin(fy, fz), ey = vmin(fx, fz), ez = vmin(fx, fy);          // exits of the other two axes, all >= 0
     if (nx + fabs(nx) * 0x1p-48 <= ex && ny + fabs(ny) * 0x1p-48 <= ey && nz + fabs(nz) * 0x1p-48 <= ez) return true;
     if (nx > ex + ex * 0x1p-48 || ny > ey + ey * 0x1p-48 || nz > ez + ez * 0x1p-48) return false;
     return box_hit_exact(lo, hi, r);

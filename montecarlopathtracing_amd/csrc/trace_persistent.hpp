@@ -20,7 +20,7 @@
 namespace mcpt {
 
 #ifndef MCPT_REFILL_LANES
-#define MCPT_REFILL_LANES 16        /* refill as soon as this many lanes are idle */
+#define MCPT_REFILL_LANES 24        /* refill as soon as this many lanes are idle (sweep: 8: +6 %, 16: +1 %, 32: +1 %) */
 #endif
 #ifndef MCPT_INNER_BURST
 #define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
