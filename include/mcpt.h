@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCPT_VERSION 100
+#define MCPT_VERSION 101
 
 #define MCPT_OK             0
 #define MCPT_ERR_IO        -1   /* a scene/texture/output file could not be opened */
@@ -91,6 +91,18 @@ int         mcpt_device_count(void);                        /* number of HIP dev
 /* Reads <path><filename>.obj/.mtl/.camera exactly like read_scene; textures named by map_Kd are looked up
  * relative to <path> first, then the cwd (reference: cwd only). */
 int  mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out);
+/* The same with opt-in departures from the reference's reader; load_flags = 0 is mcpt_scene_load.
+ * The reference's read_obj (MTPC/sceneManagement.cpp:76-189) takes the 2nd index of a face corner as the normal and the
+ * 3rd as the texture coordinate, reads triangles only, ignores mtllib, and its Morton domain is the fixed cube [-1,4]^3
+ * (MTPC/morton code.h:6-7). */
+#define MCPT_LOAD_STANDARD_OBJ   1   /* corners v, v/vt, v//vn, v/vt/vn as the OBJ format defines them; relative (negative)
+                                        indices; polygons fan-triangulated; any run of blanks separates fields; a corner
+                                        without vn gets the face normal, without vt (0,0) */
+#define MCPT_LOAD_MTLLIB         2   /* read the .mtl files named by the .obj's mtllib lines (next to the .obj);
+                                        <filename>.mtl only when it names none */
+#define MCPT_LOAD_MORTON_BOUNDS  4   /* Morton keys on the scene's bounding box (changes the leaf order, i.e. which of two
+                                        equidistant triangles wins a tie; everything else is unchanged) */
+int  mcpt_scene_load_ex(const char* path, const char* filename, int32_t load_flags, mcpt_scene** out);
 void mcpt_scene_free(mcpt_scene*);
 /* The same scene_data from arrays instead of files (generated scenes: the 10 M-triangle stress scene would be ~1 GB of
  * .obj text).  Faces are given in the order the .obj would list them; Face::norm, Morton keys, per-material face
@@ -172,6 +184,17 @@ int  mcpt_quantize_rgb8(const double* img, int64_t n, uint8_t* rgb8);        /* 
 int  mcpt_write_png(const char* file, const uint8_t* rgb8, int32_t width, int32_t height);
 int64_t mcpt_png_encode(const uint8_t* rgb8, int32_t width, int32_t height, uint8_t* out, int64_t cap);
 
+/* Output beyond svpng.  mcpt_png_encode_deflate / mcpt_write_png_deflate: the same 8-bit RGB picture as a
+ * compressed PNG (per-row filter choice + deflate).  mcpt_write_pfm: img = double[h*w*3] as generateImg leaves it, written as
+ * a little-endian fp32 Portable Float Map (bottom row first), no clamp.  Checkpoints: the fp64 frame plus the finished ones
+ * of `parts` tile partitions (mcpt_render_params.rank/world = part/parts); load returns MCPT_ERR_IO when there is no file
+ * and MCPT_ERR_PARSE when the file belongs to another frame (size, spp, seed, parts or scene differ). */
+int64_t mcpt_png_encode_deflate(const uint8_t* rgb8, int32_t width, int32_t height, uint8_t* out, int64_t cap);
+int  mcpt_write_png_deflate(const char* file, const uint8_t* rgb8, int32_t width, int32_t height);
+int  mcpt_write_pfm(const char* file, const double* img, int32_t width, int32_t height);
+int  mcpt_checkpoint_save(const char* file, const mcpt_scene* scene, const double* img, int32_t spp, uint64_t seed, int32_t parts, const uint8_t* done);
+int  mcpt_checkpoint_load(const char* file, const mcpt_scene* scene, double* img, int32_t spp, uint64_t seed, int32_t parts, uint8_t* done);
+
 /* Texture input (what the reference gets from cv::imread, MTPC/sceneManagement.h:137): decodes a baseline or progressive
  * JFIF file into an 8-bit BGR raster (rows x cols x 3).  With bgr == NULL only the size is returned. */
 int  mcpt_decode_jpeg(const char* file, int32_t* width, int32_t* height, uint8_t* bgr, int64_t cap);
@@ -180,12 +203,21 @@ int  mcpt_decode_jpeg(const char* file, int32_t* width, int32_t* height, uint8_t
 /* Reads <path><filename>.*, renders with N samples per pixel on GPU 0 and writes
  * "../result/<filename>-SPP<N>.png" relative to the cwd, like the reference. */
 int  mcpt_render_scene(const char* path, const char* filename, int32_t spp);
+#define MCPT_OUT_PNG_DEFLATE  1      /* the .png is deflate-compressed (same pixels; the reference's svpng stores them raw) */
+#define MCPT_OUT_PFM          2      /* also write <prefix>-SPP<N>.pfm: the linear fp32 radiance before imshow's clamp */
 typedef struct {
     uint64_t seed;
     int32_t  device;            /* HIP ordinal */
     int32_t  width, height;     /* >0 overrides the .camera resolution */
     int32_t  quiet;             /* suppress the reference-style progress prints */
     const char* output_prefix;  /* NULL -> "../result/<filename>"; file = <prefix>-SPP<N>.png */
+    /* since MCPT_VERSION 101 (all zero = the reference's behaviour): */
+    int32_t  load_flags;        /* MCPT_LOAD_* */
+    int32_t  output_flags;      /* MCPT_OUT_* */
+    const char* checkpoint;     /* a file: the frame is rendered in checkpoint_parts tile partitions, the fp64 frame is saved
+                                   after each, and a run that finds a matching file resumes after the partitions it holds */
+    int32_t  checkpoint_parts;  /* 0 -> 8 */
+    int32_t  reserved;
 } mcpt_render_scene_options;
 int  mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options*, mcpt_stats* stats);
 

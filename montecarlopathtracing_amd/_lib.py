@@ -58,20 +58,23 @@ class SceneDesc(C.Structure):
 
 class RenderSceneOptions(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
-                ("quiet", C.c_int32), ("output_prefix", C.c_char_p)]
+                ("quiet", C.c_int32), ("output_prefix", C.c_char_p),
+                ("load_flags", C.c_int32), ("output_flags", C.c_int32), ("checkpoint", C.c_char_p),
+                ("checkpoint_parts", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/mcpt.h declares
 EXPORTS = [
     "mcpt_version", "mcpt_last_error", "mcpt_device_count",
-    "mcpt_scene_load", "mcpt_scene_create", "mcpt_scene_free", "mcpt_scene_set_resolution", "mcpt_scene_get_info", "mcpt_scene_get_faces",
+    "mcpt_scene_load", "mcpt_scene_load_ex", "mcpt_scene_create", "mcpt_scene_free", "mcpt_scene_set_resolution", "mcpt_scene_get_info", "mcpt_scene_get_faces",
     "mcpt_scene_get_leaf_order", "mcpt_scene_get_bvh_nodes", "mcpt_scene_find_index", "mcpt_scene_get_material",
     "mcpt_scene_get_light", "mcpt_morton_code", "mcpt_scene_fast_bvh_stats",
     "mcpt_device_create", "mcpt_device_create_ex", "mcpt_device_get_bvh_nodes", "mcpt_device_get_leaf_order", "mcpt_device_free",
     "mcpt_device_set_trace_mode",
     "mcpt_trace_closest", "mcpt_trace_closest_device",
     "mcpt_render", "mcpt_render_device", "mcpt_sample_radiance", "mcpt_owned_pixels",
-    "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_decode_jpeg",
+    "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_png_encode_deflate", "mcpt_write_png_deflate", "mcpt_write_pfm",
+    "mcpt_checkpoint_save", "mcpt_checkpoint_load", "mcpt_decode_jpeg",
     "mcpt_render_scene", "mcpt_render_scene_ex",
 ]
 
@@ -98,6 +101,7 @@ def lib():
     L.mcpt_last_error.restype = C.c_char_p
     L.mcpt_device_count.restype = C.c_int
     L.mcpt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(P)]
+    L.mcpt_scene_load_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(P)]
     L.mcpt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.POINTER(P)]
     L.mcpt_scene_free.argtypes = [P]
     L.mcpt_scene_free.restype = None
@@ -130,6 +134,12 @@ def lib():
     L.mcpt_write_png.argtypes = [C.c_char_p, U8, C.c_int32, C.c_int32]
     L.mcpt_png_encode.restype = C.c_int64
     L.mcpt_png_encode.argtypes = [U8, C.c_int32, C.c_int32, U8, C.c_int64]
+    L.mcpt_png_encode_deflate.restype = C.c_int64
+    L.mcpt_png_encode_deflate.argtypes = [U8, C.c_int32, C.c_int32, U8, C.c_int64]
+    L.mcpt_write_png_deflate.argtypes = [C.c_char_p, U8, C.c_int32, C.c_int32]
+    L.mcpt_write_pfm.argtypes = [C.c_char_p, D, C.c_int32, C.c_int32]
+    L.mcpt_checkpoint_save.argtypes = [C.c_char_p, P, D, C.c_int32, C.c_uint64, C.c_int32, U8]
+    L.mcpt_checkpoint_load.argtypes = [C.c_char_p, P, D, C.c_int32, C.c_uint64, C.c_int32, U8]
     L.mcpt_decode_jpeg.argtypes = [C.c_char_p, I32, I32, U8, C.c_int64]
     L.mcpt_render_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     L.mcpt_render_scene_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(RenderSceneOptions), C.POINTER(Stats)]

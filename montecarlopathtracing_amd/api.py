@@ -10,6 +10,8 @@ from ._lib import McptError, RenderParams, RenderSceneOptions, SceneDesc, SceneI
 
 TRACE_FAST, TRACE_REFERENCE = 0, 1
 RENDER_DEFAULT, RENDER_MEGAKERNEL = 0, 2
+LOAD_STANDARD_OBJ, LOAD_MTLLIB, LOAD_MORTON_BOUNDS = 1, 2, 4
+OUT_PNG_DEFLATE, OUT_PFM = 1, 2
 BUILD_HOST, BUILD_DEVICE = 0, 1
 SCENE_DEFER_BUILD = 1
 
@@ -25,9 +27,10 @@ def device_count():
 class Scene:
     """scene_data::read_scene + Morton sort + BVH::BVH (MTPC/MTPC.cpp:38-45)."""
 
-    def __init__(self, path, filename, width=None, height=None):
+    def __init__(self, path, filename, width=None, height=None, load_flags=0):
+        """load_flags: LOAD_STANDARD_OBJ | LOAD_MTLLIB | LOAD_MORTON_BOUNDS (opt-in; 0 = the reference's reader)."""
         self._h = C.c_void_p()
-        check(lib().mcpt_scene_load(path.encode(), filename.encode(), C.byref(self._h)))
+        check(lib().mcpt_scene_load_ex(path.encode(), filename.encode(), load_flags, C.byref(self._h)))
         if width is not None:
             self.set_resolution(width, height)
 
@@ -237,10 +240,44 @@ def png_bytes(rgb8):
     return out[:n].tobytes()
 
 
-def write_png(file, rgb8):
+def write_png(file, rgb8, deflate=False):
     rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
     h, w, _ = rgb8.shape
-    check(lib().mcpt_write_png(file.encode(), _p(rgb8, C.c_uint8), w, h))
+    check((lib().mcpt_write_png_deflate if deflate else lib().mcpt_write_png)(file.encode(), _p(rgb8, C.c_uint8), w, h))
+
+
+def png_bytes_deflate(rgb8):
+    """The same picture as a compressed PNG (per-row filters + deflate)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    cap = 1024 + h * (w * 3 + 1) * 2
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().mcpt_png_encode_deflate(_p(rgb8, C.c_uint8), w, h, _p(out, C.c_uint8), cap)
+    if n < 0:
+        check(int(n))
+    return out[:n].tobytes()
+
+
+def write_pfm(file, img):
+    """Linear radiance [H,W,3] as a little-endian fp32 Portable Float Map."""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    h, w, _ = img.shape
+    check(lib().mcpt_write_pfm(file.encode(), _p(img, C.c_double), w, h))
+
+
+def checkpoint_save(file, scene, img, spp, seed, done):
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    done = np.ascontiguousarray(done, dtype=np.uint8)
+    check(lib().mcpt_checkpoint_save(file.encode(), scene._h, _p(img, C.c_double), spp, seed, done.shape[0], _p(done, C.c_uint8)))
+
+
+def checkpoint_load(file, scene, spp, seed, parts):
+    """(img [H,W,3], done [parts]) of a matching checkpoint; McptError (code ERR_IO / ERR_PARSE) otherwise."""
+    i = scene.info
+    img = np.zeros((i.height, i.width, 3))
+    done = np.zeros(parts, dtype=np.uint8)
+    check(lib().mcpt_checkpoint_load(file.encode(), scene._h, _p(img, C.c_double), spp, seed, parts, _p(done, C.c_uint8)))
+    return img, done
 
 
 def decode_jpeg(file):
@@ -257,9 +294,11 @@ def morton_code(x, y, z):
     return lib().mcpt_morton_code(x, y, z)
 
 
-def render_scene(path, filename, N_ray_per_pixel, seed=0, device=0, width=0, height=0, quiet=True, output_prefix=None, stats=None):
+def render_scene(path, filename, N_ray_per_pixel, seed=0, device=0, width=0, height=0, quiet=True, output_prefix=None, stats=None,
+                 load_flags=0, output_flags=0, checkpoint=None, checkpoint_parts=0):
     """render_scene(path, filename, N) of MTPC/MTPC.cpp:35; writes <prefix>-SPP<N>.png (default ../result/<filename>)."""
-    o = RenderSceneOptions(seed, device, width, height, int(quiet), output_prefix.encode() if output_prefix else None)
+    o = RenderSceneOptions(seed, device, width, height, int(quiet), output_prefix.encode() if output_prefix else None,
+                           load_flags, output_flags, checkpoint.encode() if checkpoint else None, checkpoint_parts, 0)
     check(lib().mcpt_render_scene_ex(path.encode(), filename.encode(), N_ray_per_pixel, C.byref(o),
                                      C.byref(stats) if stats is not None else None))
     return True

@@ -27,15 +27,16 @@ __device__ __forceinline__ uint32_t quant10(float unit)
 }
 
 // key of face i = getMortonCode(centre), centre = ((v1+v2)+v3)/3 in fp64, narrowed to float at the call
-__global__ void k_morton_keys(const double* __restrict__ v9, int t, uint32_t* __restrict__ keys, int32_t* __restrict__ idx)
+struct MortonDomain { float lo[3], span[3]; };
+__global__ void k_morton_keys(const double* __restrict__ v9, int t, MortonDomain dom, uint32_t* __restrict__ keys, int32_t* __restrict__ idx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t) return;
     const double* p = v9 + (size_t)i * 9;
     const float cx = (float)(((p[0] + p[3]) + p[6]) / 3), cy = (float)(((p[1] + p[4]) + p[7]) / 3), cz = (float)(((p[2] + p[5]) + p[8]) / 3);
-    const uint32_t xx = spread3(quant10((cx - (-1.0f)) / 5.0f));
-    const uint32_t yy = spread3(quant10((cy - (-1.0f)) / 5.0f));
-    const uint32_t zz = spread3(quant10((cz - (-1.0f)) / 5.0f));
+    const uint32_t xx = spread3(quant10((cx - dom.lo[0]) / dom.span[0]));      // reference: lo = -1, span = 5
+    const uint32_t yy = spread3(quant10((cy - dom.lo[1]) / dom.span[1]));
+    const uint32_t zz = spread3(quant10((cz - dom.lo[2]) / dom.span[2]));
     keys[i] = xx * 4 + yy * 2 + zz;
     idx[i] = i;
 }
@@ -110,7 +111,9 @@ hipError_t device_build_reference(const BuildInputs& in, const mcpt_bvh_info& bi
     auto cleanup = [&]() { (void)hipFree(keys); (void)hipFree(keys_out); (void)hipFree(idx); (void)hipFree(tmp); };
     if ((rc = hipMalloc(reinterpret_cast<void**>(&keys), size_t(t) * 4)) != hipSuccess || (rc = hipMalloc(reinterpret_cast<void**>(&keys_out), size_t(t) * 4)) != hipSuccess ||
         (rc = hipMalloc(reinterpret_cast<void**>(&idx), size_t(t) * 4)) != hipSuccess) { cleanup(); return rc; }
-    hipLaunchKernelGGL(k_morton_keys, dim3((t + 255) / 256), dim3(256), 0, st, in.v9, t, keys, idx);
+    MortonDomain dom;
+    for (int a = 0; a < 3; a++) { dom.lo[a] = in.morton_lo[a]; dom.span[a] = in.morton_span[a]; }
+    hipLaunchKernelGGL(k_morton_keys, dim3((t + 255) / 256), dim3(256), 0, st, in.v9, t, dom, keys, idx);
     // stable LSD radix sort of (key, face index) on the 30 key bits: equal keys keep .obj order (D2)
     rc = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, idx, d_order, t, 0, 30, st);
     if (rc == hipSuccess) rc = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);

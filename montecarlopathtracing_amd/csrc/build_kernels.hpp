@@ -14,6 +14,7 @@ struct BuildInputs {            // faces in .obj order, device pointers
     const double* nrm3;         // [t][3]  Face::norm
     const int32_t* material;    // [t]
     int t;
+    float morton_lo[3], morton_span[3];     // key domain (Scene::morton_lo / morton_span)
 };
 
 // fills nodes[Nr] (compact level order), tris[t], shade[t] (leaf order) and d_order[t] (leaf -> .obj face)

@@ -49,6 +49,15 @@ uint32_t morton_code(float x, float y, float z)
     return xx * 4 + yy * 2 + zz;
 }
 
+// the same key on another axis-aligned domain (MCPT_LOAD_MORTON_BOUNDS); lo = -1, span = 5 gives morton_code()
+uint32_t morton_code_in(float x, float y, float z, const float lo[3], const float span[3])
+{
+    const uint32_t xx = spread3(quantize10((x - lo[0]) / span[0]));
+    const uint32_t yy = spread3(quantize10((y - lo[1]) / span[1]));
+    const uint32_t zz = spread3(quantize10((z - lo[2]) / span[2]));
+    return xx * 4 + yy * 2 + zz;
+}
+
 // BVH::findIndex (BVH.cpp:99-104): implicit index -> compact index = i - (virtual nodes above level l)
 int find_index(const mcpt_bvh_info& b, int i, int l)
 {

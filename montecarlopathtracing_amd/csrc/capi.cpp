@@ -107,13 +107,16 @@ int mcpt_device_count(void)
 }
 
 // ------------------------------------------------------------------------------------------------ scene
-int mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out)
+int mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out) { return mcpt_scene_load_ex(path, filename, 0, out); }
+
+int mcpt_scene_load_ex(const char* path, const char* filename, int32_t load_flags, mcpt_scene** out)
 {
     if (!path || !filename || !out) return fail(MCPT_ERR_ARG, "null argument");
     *out = nullptr;
+    if (load_flags & ~(MCPT_LOAD_STANDARD_OBJ | MCPT_LOAD_MTLLIB | MCPT_LOAD_MORTON_BOUNDS)) return fail(MCPT_ERR_ARG, "unknown load flag");
     std::unique_ptr<mcpt_scene> h(new mcpt_scene);
     std::string err;
-    int rc = load_scene_files(path, filename, h->s, err);
+    int rc = load_scene_files(path, filename, load_flags, h->s, err);
     if (rc) return fail(rc, err);
     rc = build_accel(h->s, err);
     if (rc) return fail(rc, err);
@@ -479,7 +482,8 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->shade), size_t(t) * sizeof(DTriShade));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->d_order), size_t(t) * sizeof(int32_t));
         if (e == hipSuccess) {
-            BuildInputs in{d_v9, d_vn9, d_vt6, d_nrm3, d_mat, t};
+            BuildInputs in{d_v9, d_vn9, d_vt6, d_nrm3, d_mat, t, {s.morton_lo[0], s.morton_lo[1], s.morton_lo[2]},
+                           {s.morton_span[0], s.morton_span[1], s.morton_span[2]}};
             e = device_build_reference(in, bi, d->nodes, d->tris, d->shade, d->d_order, d->stream);
         }
         order.resize(t);
@@ -992,6 +996,56 @@ int mcpt_write_png(const char* file, const uint8_t* rgb8, int32_t w, int32_t h)
     return ok ? MCPT_OK : fail(MCPT_ERR_IO, std::string("short write to ") + file);
 }
 
+int64_t mcpt_png_encode_deflate(const uint8_t* rgb8, int32_t w, int32_t h, uint8_t* out, int64_t cap)
+{
+    if (!rgb8 || w <= 0 || h <= 0) { fail(MCPT_ERR_ARG, "bad argument"); return MCPT_ERR_ARG; }
+    const int64_t n = png_encode_deflate(rgb8, w, h, out, cap);
+    if (n < 0) { fail(MCPT_ERR_ARG, "png: buffer too small"); return MCPT_ERR_ARG; }
+    return n;
+}
+
+int mcpt_write_png_deflate(const char* file, const uint8_t* rgb8, int32_t w, int32_t h)
+{
+    if (!file || !rgb8 || w <= 0 || h <= 0) return fail(MCPT_ERR_ARG, "bad argument");
+    const int64_t need = png_encode_deflate(rgb8, w, h, nullptr, 0);
+    std::vector<uint8_t> buf(static_cast<size_t>(need));
+    const int64_t n = png_encode_deflate(rgb8, w, h, buf.data(), need);
+    if (n != need) return fail(MCPT_ERR_ARG, "png: encoder size mismatch");
+    FILE* fp = std::fopen(file, "wb");
+    if (!fp) return fail(MCPT_ERR_IO, std::string("cannot open ") + file);
+    const bool ok = std::fwrite(buf.data(), 1, size_t(n), fp) == size_t(n);
+    return (std::fclose(fp) == 0 && ok) ? MCPT_OK : fail(MCPT_ERR_IO, std::string("short write to ") + file);
+}
+
+int mcpt_write_pfm(const char* file, const double* img, int32_t w, int32_t h)
+{
+    if (!file || !img || w <= 0 || h <= 0) return fail(MCPT_ERR_ARG, "bad argument");
+    std::string err;
+    const int rc = write_pfm(file, img, w, h, err);
+    return rc ? fail(rc, err) : MCPT_OK;
+}
+
+static uint64_t scene_tag(const Scene& s)
+{
+    return (uint64_t(s.faces.size()) * 0x9E3779B97F4A7C15ull) ^ (uint64_t(s.materials.size()) << 40) ^ (uint64_t(s.lights.size()) << 52);
+}
+
+int mcpt_checkpoint_save(const char* file, const mcpt_scene* h, const double* img, int32_t spp, uint64_t seed, int32_t parts, const uint8_t* done)
+{
+    if (!file || !h || !img || !done || spp <= 0 || parts <= 0 || parts > 65536) return fail(MCPT_ERR_ARG, "bad argument");
+    std::string err;
+    const int rc = checkpoint_save(file, img, h->s.width, h->s.height, spp, seed, scene_tag(h->s), parts, done, err);
+    return rc ? fail(rc, err) : MCPT_OK;
+}
+
+int mcpt_checkpoint_load(const char* file, const mcpt_scene* h, double* img, int32_t spp, uint64_t seed, int32_t parts, uint8_t* done)
+{
+    if (!file || !h || !img || !done || spp <= 0 || parts <= 0 || parts > 65536) return fail(MCPT_ERR_ARG, "bad argument");
+    std::string err;
+    const int rc = checkpoint_load(file, img, h->s.width, h->s.height, spp, seed, scene_tag(h->s), parts, done, err);
+    return rc ? fail(rc, err) : MCPT_OK;
+}
+
 int mcpt_decode_jpeg(const char* file, int32_t* width, int32_t* height, uint8_t* bgr, int64_t cap)
 {
     if (!file || !width || !height) return fail(MCPT_ERR_ARG, "null argument");
@@ -1017,7 +1071,7 @@ int mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, co
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     mcpt_scene* sc = nullptr;
-    int rc = mcpt_scene_load(path, filename, &sc);
+    int rc = mcpt_scene_load_ex(path, filename, o.load_flags, &sc);
     if (rc) return rc;
     if (o.width > 0 && o.height > 0) mcpt_scene_set_resolution(sc, o.width, o.height);
     const Scene& s = sc->s;
@@ -1035,15 +1089,45 @@ int mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, co
     mcpt_render_params rp{};
     rp.spp = spp; rp.seed = o.seed; rp.world = 1;
     mcpt_stats local{};
-    rc = mcpt_render(dev, &rp, img.data(), &local);
+    if (!o.checkpoint) {
+        rc = mcpt_render(dev, &rp, img.data(), &local);
+    } else {
+        // the frame in `parts` tile partitions, saved after each; partitions a matching checkpoint already holds are skipped
+        const int parts = o.checkpoint_parts > 0 ? o.checkpoint_parts : 8;
+        std::vector<uint8_t> done(size_t(parts), 0);
+        const int lrc = mcpt_checkpoint_load(o.checkpoint, sc, img.data(), spp, o.seed, parts, done.data());
+        if (lrc != MCPT_OK) { std::fill(img.begin(), img.end(), 0.0); std::fill(done.begin(), done.end(), uint8_t(0)); }
+        if (talk && lrc == MCPT_OK) {
+            int have = 0;
+            for (uint8_t v : done) have += v ? 1 : 0;
+            std::printf("resuming from %s: %d of %d partitions done\n", o.checkpoint, have, parts);
+        }
+        rp.world = parts;
+        for (int part = 0; part < parts && rc == MCPT_OK; part++) {
+            if (done[size_t(part)]) continue;
+            rp.rank = part;
+            mcpt_stats one{};
+            rc = mcpt_render(dev, &rp, img.data(), &one);
+            if (rc != MCPT_OK) break;
+            local.rays_primary += one.rays_primary; local.rays_shadow += one.rays_shadow; local.rays_bounce += one.rays_bounce;
+            local.node_visits += one.node_visits; local.tri_tests += one.tri_tests; local.shade_calls += one.shade_calls;
+            local.samples += one.samples; local.shadow_skipped += one.shadow_skipped; local.ms_trace += one.ms_trace;
+            local.ms_total += one.ms_total; local.launches += one.launches;
+            local.max_depth = std::max(local.max_depth, one.max_depth);
+            done[size_t(part)] = 1;
+            rc = mcpt_checkpoint_save(o.checkpoint, sc, img.data(), spp, o.seed, parts, done.data());
+        }
+    }
     const auto t2 = clk::now();
     if (rc == MCPT_OK) {
         if (talk) std::printf("Phase 2(ray tracing) = %.3f ms\n", std::chrono::duration<double, std::milli>(t2 - t1).count());
         std::vector<uint8_t> rgb(img.size());
         mcpt_quantize_rgb8(img.data(), int64_t(img.size()), rgb.data());
         const std::string prefix = o.output_prefix ? std::string(o.output_prefix) : std::string("../result/") + filename;
-        const std::string file = prefix + "-SPP" + std::to_string(spp) + ".png";       // imshow, MTPC.cpp:17-20
-        rc = mcpt_write_png(file.c_str(), rgb.data(), s.width, s.height);
+        const std::string stem = prefix + "-SPP" + std::to_string(spp);                 // imshow, MTPC.cpp:17-20
+        rc = (o.output_flags & MCPT_OUT_PNG_DEFLATE) ? mcpt_write_png_deflate((stem + ".png").c_str(), rgb.data(), s.width, s.height)
+                                                      : mcpt_write_png((stem + ".png").c_str(), rgb.data(), s.width, s.height);
+        if (rc == MCPT_OK && (o.output_flags & MCPT_OUT_PFM)) rc = mcpt_write_pfm((stem + ".pfm").c_str(), img.data(), s.width, s.height);
     }
     if (stats) *stats = local;
     mcpt_device_free(dev);

@@ -68,16 +68,19 @@ struct Scene {
     mcpt_bvh_info bi{};
     std::vector<NodeBox> nodes;           // Nr real nodes, compact level order
     std::vector<int32_t> node_level, node_leaf;
+    float morton_lo[3] = {-1.0f, -1.0f, -1.0f};   // Morton domain: the reference's fixed [-1,4]^3 (morton code.h:6-7) unless
+    float morton_span[3] = {5.0f, 5.0f, 5.0f};    // the scene was loaded with MCPT_LOAD_MORTON_BOUNDS
     double area0 = 0;                     // total area of lights[0] (Q1)
     bool accel_built = false;             // false: Morton sort + BVH are left to the device (mcpt_device_create_ex)
 };
 
 // scene_loader.cpp
-int load_scene_files(const std::string& path, const std::string& filename, Scene& out, std::string& err);
+int load_scene_files(const std::string& path, const std::string& filename, int load_flags, Scene& out, std::string& err);
 int finish_scene(Scene& s, const std::string& what, std::string& err);
 int find_material(const Scene& s, const std::string& name);
 // bvh_build.cpp
 uint32_t morton_code(float x, float y, float z);
+uint32_t morton_code_in(float x, float y, float z, const float lo[3], const float span[3]);
 int find_index(const mcpt_bvh_info& b, int i, int l);
 bool has_right_child(const mcpt_bvh_info& b, int node, int l);
 int build_accel(Scene& s, std::string& err);
@@ -85,6 +88,13 @@ mcpt_bvh_info bvh_shape(int t);
 double face_area(const FaceRec& f);
 // png_writer.cpp
 int64_t png_encode(const uint8_t* rgb8, int w, int h, uint8_t* out, int64_t cap);
+// output_formats.cpp
+int64_t png_encode_deflate(const uint8_t* rgb8, int w, int h, uint8_t* out, int64_t cap);
+int write_pfm(const char* file, const double* img, int w, int h, std::string& err);
+int checkpoint_save(const char* file, const double* img, int w, int h, int spp, uint64_t seed, uint64_t scene_tag, int parts,
+                    const uint8_t* done, std::string& err);
+int checkpoint_load(const char* file, double* img, int w, int h, int spp, uint64_t seed, uint64_t scene_tag, int parts, uint8_t* done,
+                    std::string& err);
 // camera frame of generateImg (pathTracing.cpp:276-294), shared by host and device code
 struct CameraFrame { Vec3 eye, start_point, screen_pdx, screen_pdy; };
 CameraFrame camera_frame(const Scene& s);

@@ -7,6 +7,11 @@
 // (the .mtl name is derived from the scene name), per-material face lists in .obj order.
 // Deliberate differences: '\r' stripped (D4), Ns/Ni default 1 (D8), malformed input returns an error
 // instead of dereferencing NULL, textures are searched next to the scene before the cwd.
+// Opt-in (mcpt_scene_load_ex; parity mode = no flag): MCPT_LOAD_STANDARD_OBJ reads faces the way the OBJ
+// format defines them (v, v/vt, v//vn, v/vt/vn; relative indices; polygons as fans; any run of blanks separates fields),
+// MCPT_LOAD_MTLLIB reads the .mtl files the .obj names, MCPT_LOAD_MORTON_BOUNDS keys the Morton order on the scene's own
+// bounding box instead of the fixed [-1,4]^3 that clamps most of veach-mis into a few cells.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -139,14 +144,105 @@ int read_mtl(const std::string& file, const std::string& dir, Scene& s, std::str
     return MCPT_OK;
 }
 
+// one face into the scene (Face::calNorm and the Morton key of its centre, sceneManagement.cpp:176-179, :408-412)
+void push_face(Scene& s, FaceRec f, int material)
+{
+    f.material = material;
+    f.nrm = normalized(cross(f.v[0] - f.v[1], f.v[2] - f.v[0]));
+    const Vec3 center = (f.v[0] + f.v[1] + f.v[2]) / 3;
+    f.morton = morton_code(float(center.x), float(center.y), float(center.z));
+    s.materials[material].faces.push_back(int32_t(s.faces.size()));
+    s.faces.push_back(f);
+}
+
+// MCPT_LOAD_STANDARD_OBJ: "f" with any number of corners, each v, v/vt, v//vn or v/vt/vn, 1-based or negative (relative to
+// the end of the list so far).  Polygons become the fan (0, i, i+1).  A corner without vn gets the face normal, without
+// vt the texture coordinate (0, 0).
+int standard_face(const std::string& rest, Scene& s, int material, std::string& err)
+{
+    struct Corner { long v, t, n; };
+    std::vector<Corner> cs;
+    const char* p = rest.c_str();
+    auto resolve = [](long i, size_t n) -> long { return i > 0 ? i - 1 : (i < 0 ? long(n) + i : -1); };
+    while (*p) {
+        while (*p == ' ' || *p == '\t') p++;
+        if (!*p) break;
+        char* end = nullptr;
+        Corner c{-1, -1, -1};
+        long v = std::strtol(p, &end, 10);
+        if (end == p) { err = "face " + std::to_string(s.faces.size()) + ": bad corner '" + std::string(p) + "'"; return MCPT_ERR_PARSE; }
+        c.v = resolve(v, s.v.size());
+        p = end;
+        if (*p == '/') {
+            p++;
+            if (*p != '/' && *p != ' ' && *p != '\t' && *p) { long t = std::strtol(p, &end, 10); if (end != p) { c.t = resolve(t, s.vt.size()); if (c.t < 0) c.t = -2; } p = end; }
+            if (*p == '/') { p++; long n = std::strtol(p, &end, 10); if (end != p) { c.n = resolve(n, s.vn.size()); if (c.n < 0) c.n = -2; } p = end; }
+        }
+        if (c.v < 0 || c.v >= long(s.v.size()) || c.t == -2 || c.t >= long(s.vt.size()) || c.n == -2 || c.n >= long(s.vn.size())) {
+            err = "face " + std::to_string(s.faces.size()) + ": index out of range";
+            return MCPT_ERR_PARSE;
+        }
+        cs.push_back(c);
+    }
+    if (cs.size() < 3) { err = "face " + std::to_string(s.faces.size()) + ": fewer than three corners"; return MCPT_ERR_PARSE; }
+    for (size_t i = 1; i + 1 < cs.size(); i++) {
+        const Corner tri[3] = {cs[0], cs[i], cs[i + 1]};
+        FaceRec f{};
+        for (int k = 0; k < 3; k++) f.v[k] = s.v[size_t(tri[k].v)];
+        const Vec3 flat = normalized(cross(f.v[0] - f.v[1], f.v[2] - f.v[0]));
+        for (int k = 0; k < 3; k++) {
+            f.vn[k] = tri[k].n >= 0 ? s.vn[size_t(tri[k].n)] : flat;
+            f.vt[k][0] = tri[k].t >= 0 ? s.vt[size_t(tri[k].t)].first : 0.0;
+            f.vt[k][1] = tri[k].t >= 0 ? s.vt[size_t(tri[k].t)].second : 0.0;
+        }
+        push_face(s, f, material);
+    }
+    return MCPT_OK;
+}
+
+// whitespace-tolerant "x y z" (MCPT_LOAD_STANDARD_OBJ); missing numbers read as 0
+Vec3 three_numbers_free(const std::string& t)
+{
+    const char* p = t.c_str();
+    char* end = nullptr;
+    double q[3] = {0, 0, 0};
+    for (int i = 0; i < 3; i++) { q[i] = std::strtod(p, &end); if (end == p) break; p = end; }
+    return Vec3{q[0], q[1], q[2]};
+}
+
 // scene_data::read_obj, sceneManagement.cpp:76-189
-int read_obj(const std::string& file, Scene& s, std::string& err)
+int read_obj(const std::string& file, int load_flags, Scene& s, std::string& err)
 {
     std::ifstream in(file);
     if (!in) { err = "cannot open " + file; return MCPT_ERR_IO; }
     std::string line;
     int material = -1;
+    const bool standard = (load_flags & MCPT_LOAD_STANDARD_OBJ) != 0;
     while (next_line(in, line)) {
+        if (standard) {
+            size_t b = line.find_first_not_of(" \t");
+            if (b == std::string::npos || line[b] == '#') continue;
+            if (b) line = line.substr(b);
+            const bool sep2 = line.size() > 2 && (line[2] == ' ' || line[2] == '\t');
+            const bool sep1 = line.size() > 1 && (line[1] == ' ' || line[1] == '\t');
+            if (line[0] == 'v' && sep1) { s.v.push_back(three_numbers_free(line.substr(2))); continue; }
+            if (line[0] == 'v' && line.size() > 1 && line[1] == 'n' && sep2) { s.vn.push_back(three_numbers_free(line.substr(3))); continue; }
+            if (line[0] == 'v' && line.size() > 1 && line[1] == 't' && sep2) { const Vec3 q = three_numbers_free(line.substr(3)); s.vt.emplace_back(q.x, q.y); continue; }
+            if (line[0] == 'f' && sep1) {
+                if (material < 0) { err = "face before any usemtl"; return MCPT_ERR_PARSE; }
+                const int rc = standard_face(line.substr(2), s, material, err);
+                if (rc) return rc;
+                continue;
+            }
+            if (has_prefix(line, "usemtl")) {
+                std::string name = tail(line, 7);
+                const size_t nb = name.find_first_not_of(" \t"), ne = name.find_last_not_of(" \t");
+                name = nb == std::string::npos ? std::string() : name.substr(nb, ne - nb + 1);
+                material = find_material(s, name);
+                if (material < 0) { err = "usemtl '" + name + "' is not defined in the .mtl"; return MCPT_ERR_PARSE; }
+            }
+            continue;
+        }
         const char c0 = line.size() > 0 ? line[0] : '\0', c1 = line.size() > 1 ? line[1] : '\0',
                    c2 = line.size() > 2 ? line[2] : '\0';
         if (c0 == 'v' && c1 == ' ') {
@@ -197,12 +293,7 @@ int read_obj(const std::string& file, Scene& s, std::string& err)
                 f.vt[corner][0] = s.vt[it].first;   // 3rd index -> texture coordinates
                 f.vt[corner][1] = s.vt[it].second;
             }
-            f.material = material;
-            f.nrm = normalized(cross(f.v[0] - f.v[1], f.v[2] - f.v[0]));           // Face::calNorm, :408-412
-            const Vec3 center = (f.v[0] + f.v[1] + f.v[2]) / 3;                    // :176-179
-            f.morton = morton_code(float(center.x), float(center.y), float(center.z));
-            s.materials[material].faces.push_back(int32_t(s.faces.size()));
-            s.faces.push_back(f);
+            push_face(s, f, material);
         }
     }
     return MCPT_OK;
@@ -246,15 +337,53 @@ double face_area(const FaceRec& f)
 }
 
 // scene_data::read_scene, sceneManagement.cpp:264-274: .mtl, then .obj, then .camera
-int load_scene_files(const std::string& path, const std::string& filename, Scene& s, std::string& err)
+int load_scene_files(const std::string& path, const std::string& filename, int load_flags, Scene& s, std::string& err)
 {
     const std::string base = path + filename;
-    int rc = read_mtl(base + ".mtl", path, s, err);
+    int rc = MCPT_OK;
+    std::vector<std::string> libs;
+    if (load_flags & MCPT_LOAD_MTLLIB) {                 // the files the .obj names, in order; the reference ignores the lines
+        std::ifstream in(base + ".obj");
+        if (!in) { err = "cannot open " + base + ".obj"; return MCPT_ERR_IO; }
+        std::string line;
+        while (next_line(in, line)) {
+            const size_t b = line.find_first_not_of(" \t");
+            if (b == std::string::npos || line.compare(b, 7, "mtllib ") != 0) continue;
+            std::string names = line.substr(b + 7);
+            size_t pos = 0;
+            while (pos < names.size()) {
+                const size_t e = names.find(' ', pos);
+                const std::string one = names.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+                if (!one.empty()) libs.push_back(one);
+                if (e == std::string::npos) break;
+                pos = e + 1;
+            }
+        }
+    }
+    if (libs.empty()) rc = read_mtl(base + ".mtl", path, s, err);
+    for (size_t i = 0; rc == MCPT_OK && i < libs.size(); i++) rc = read_mtl(path + libs[i], path, s, err);
     if (rc) return rc;
-    rc = read_obj(base + ".obj", s, err);
+    rc = read_obj(base + ".obj", load_flags, s, err);
     if (rc) return rc;
     rc = read_camera(base + ".camera", s, err);
     if (rc) return rc;
+    if ((load_flags & MCPT_LOAD_MORTON_BOUNDS) && !s.faces.empty()) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (const FaceRec& f : s.faces)
+            for (int k = 0; k < 3; k++) {
+                const double q[3] = {f.v[k].x, f.v[k].y, f.v[k].z};
+                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); }
+            }
+        for (int a = 0; a < 3; a++) {
+            s.morton_lo[a] = float(lo[a]);
+            const float span = float(hi[a]) - s.morton_lo[a];
+            s.morton_span[a] = span > 0.0f ? span : 1.0f;
+        }
+        for (FaceRec& f : s.faces) {
+            const Vec3 c = (f.v[0] + f.v[1] + f.v[2]) / 3;
+            f.morton = morton_code_in(float(c.x), float(c.y), float(c.z), s.morton_lo, s.morton_span);
+        }
+    }
     return finish_scene(s, base, err);
 }
 

@@ -264,3 +264,72 @@ def test_device_build_equals_host_build(mcpt, name, tmp_path):
         d2.close()
     host.close()
     dev.close()
+
+
+def test_morton_bounds_scene_same_answers(mcpt, oracle):
+    """MCPT_LOAD_MORTON_BOUNDS changes the leaf order (hence the reference-shaped tree and the tie-break index k) and nothing
+    else: both walks still agree with each other, the device build still equals the host build, and against the parity-mode
+    scene every ray finds the same distance; only rays with two equidistant candidates may name the other triangle."""
+    plain = mcpt.Scene(SCENES, "veach-mis", width=96, height=54)
+    sc = mcpt.Scene(SCENES, "veach-mis", width=96, height=54, load_flags=mcpt.LOAD_MORTON_BOUNDS)
+    osc = oracle.OracleScene(SCENES + "veach-mis", texture_dir=SCENES, width=96, height=54)
+    rays = make_rays(osc, 60000, seed=11)
+    osc.close()
+    d0 = mcpt.Device(plain, 0)
+    host = mcpt.Device(sc, 0, build=mcpt.BUILD_HOST)
+    dev = mcpt.Device(sc, 0, build=mcpt.BUILD_DEVICE)
+    assert np.array_equal(dev.leaf_order(), sc.leaf_order())
+    assert np.array_equal(_bits(dev.bvh_nodes()[0]), _bits(sc.bvh_nodes()[0]))
+    f0, t0, p0, _ = d0.ray_intersect(rays)
+    f1, t1, p1, _ = host.ray_intersect(rays)
+    host.set_trace_mode(mcpt.TRACE_REFERENCE)
+    f2, t2, p2, _ = host.ray_intersect(rays)
+    assert np.array_equal(f1, f2) and np.array_equal(_bits(t1[f1 >= 0]), _bits(t2[f2 >= 0]))
+    assert np.array_equal(f0 >= 0, f1 >= 0)
+    h = f0 >= 0
+    assert np.array_equal(_bits(t0[h]), _bits(t1[h]))
+    assert (f0 != f1).mean() < 2e-3
+    a = host.generateImg(4, seed=5)
+    b = dev.generateImg(4, seed=5)
+    assert np.array_equal(_bits(a), _bits(b)) and a.sum() > 0
+    for d in (d0, host, dev):
+        d.close()
+
+
+def test_render_scene_outputs_and_resume(mcpt, tmp_path):
+    """render_scene with the output options: compressed PNG = the same pixels as the reference-format PNG, the PFM = the
+    linear frame, and a frame resumed from a checkpoint that holds 3 of 5 partitions = the uninterrupted frame, bit for bit."""
+    from PIL import Image
+    out = str(tmp_path) + os.sep
+    kw = dict(seed=9, width=80, height=60, quiet=True)
+    mcpt.render_scene(SCENES, "cornell-box", 6, output_prefix=out + "plain", **kw)
+    mcpt.render_scene(SCENES, "cornell-box", 6, output_prefix=out + "z", output_flags=mcpt.OUT_PNG_DEFLATE | mcpt.OUT_PFM, **kw)
+    a = np.array(Image.open(out + "plain-SPP6.png").convert("RGB"))
+    b = np.array(Image.open(out + "z-SPP6.png").convert("RGB"))
+    assert np.array_equal(a, b) and os.path.getsize(out + "z-SPP6.png") < os.path.getsize(out + "plain-SPP6.png")
+    sc = mcpt.Scene(SCENES, "cornell-box", width=80, height=60)
+    dev = mcpt.Device(sc, 0)
+    full = dev.generateImg(6, seed=9)
+    raw = open(out + "z-SPP6.pfm", "rb").read()
+    head = b"PF\n80 60\n-1.0\n"
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], dtype="<f4").reshape(60, 80, 3)[::-1], full.astype(np.float32))
+    assert np.array_equal(mcpt.imshow_rgb8(full), a)
+    # an interrupted run: partitions 0, 2, 3 of 5 are in the checkpoint
+    part = np.zeros_like(full)
+    for r in (0, 2, 3):
+        dev.generateImg(6, seed=9, rank=r, world=5, img=part)
+    ck = out + "frame.ckp"
+    mcpt.checkpoint_save(ck, sc, part, 6, 9, np.array([1, 0, 1, 1, 0], dtype=np.uint8))
+    st = mcpt.Stats()
+    mcpt.render_scene(SCENES, "cornell-box", 6, output_prefix=out + "resumed", checkpoint=ck, checkpoint_parts=5, stats=st, **kw)
+    assert open(out + "resumed-SPP6.png", "rb").read() == open(out + "plain-SPP6.png", "rb").read()
+    img, done = mcpt.checkpoint_load(ck, sc, 6, 9, 5)
+    assert done.all() and np.array_equal(_bits(img), _bits(full))
+    assert 0 < st.samples < 80 * 60 * 6              # only the two missing partitions were rendered
+    # a checkpoint of another frame (different seed) is ignored, not trusted
+    mcpt.render_scene(SCENES, "cornell-box", 6, output_prefix=out + "other", checkpoint=ck, checkpoint_parts=5,
+                      **dict(kw, seed=10))
+    assert open(out + "other-SPP6.png", "rb").read() != open(out + "plain-SPP6.png", "rb").read()
+    dev.close()
+    sc.close()

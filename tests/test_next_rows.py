@@ -1,0 +1,172 @@
+"""Not gpu: the opt-in rows of SURVEY 8f that live on the host -- loader hardening (#3) and the output side (#4).
+None of this exists in the reference, so there is nothing of the reference to pin it to; each feature is checked against an
+independent statement of what it must do (the same geometry written the reference's way, Pillow / zlib as PNG decoders,
+the PFM definition, a resumed frame against an uninterrupted one)."""
+import io
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+CAMERA = "eye 0 1 4\nlookat 0 1 0\nup 0 1 0\nfovy 40\nwidth 32\nheight 24\nmtlname lamp 10 10 10\n"
+MTL = "newmtl grey\nKd 0.5 0.5 0.5\nKs 0 0 0\nNs 1\nNi 1\nnewmtl lamp\nKd 0 0 0\nKs 0 0 0\n"
+
+
+def _write(d, name, obj, mtl=MTL, mtl_name=None):
+    open(os.path.join(d, name + ".obj"), "w").write(obj)
+    open(os.path.join(d, (mtl_name or name + ".mtl")), "w").write(mtl)
+    open(os.path.join(d, name + ".camera"), "w").write(CAMERA)
+
+
+def test_standard_obj_reads_the_same_geometry(mcpt, tmp_path):
+    """A quad + a triangle in the OBJ format's own conventions (v/vt/vn order, negative indices, a polygon, tabs and double
+    blanks, v//vn and bare v corners) against the same triangles written the reference's way (v/vn/vt, one blank)."""
+    d = str(tmp_path) + os.sep
+    std = ("# standard\nv  -1 0 0\nv 1 0 0\nv\t1 2 0\nv -1 2 0\nv 0 3 -1\n"
+           "vn 0 0 1\nvn 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+           "usemtl grey\nf 1/1/1 2/2/1  3/3/1 4/4/1\n"
+           "usemtl lamp\nf -3//2 -2//2 -1//2\nf 1 2 5\n")
+    _write(d, "std", std)
+    ref = ("v -1 0 0\nv 1 0 0\nv 1 2 0\nv -1 2 0\nv 0 3 -1\n"
+           "vn 0 0 1\nvn 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0 0\n"
+           "usemtl grey\nf 1/1/1 2/1/2 3/1/3\nf 1/1/1 3/1/3 4/1/4\n"
+           "usemtl lamp\nf 3/2/5 4/2/5 5/2/5\n")
+    _write(d, "ref", ref)
+    a = mcpt.Scene(d, "std", load_flags=mcpt.LOAD_STANDARD_OBJ)
+    b = mcpt.Scene(d, "ref")
+    ga, ma, ka = a.faces()
+    gb, mb, kb = b.faces()
+    assert ga.shape[0] == 4 and gb.shape[0] == 3
+    assert np.array_equal(ga[:3], gb) and np.array_equal(ma[:3], mb) and np.array_equal(ka[:3], kb)
+    # the bare-v face: flat normal on every corner, texture coordinate (0, 0)
+    v = ga[3, :9].reshape(3, 3)
+    n = np.cross(v[0] - v[1], v[2] - v[0])
+    n /= np.linalg.norm(n)
+    assert np.allclose(ga[3, 9:18].reshape(3, 3), n) and np.all(ga[3, 18:24] == 0)
+    # without the flag the standard file is read the reference's way: 2nd index = normal -> index 4 of 2 normals is refused
+    with pytest.raises(mcpt.McptError):
+        mcpt.Scene(d, "std")
+    for bad in ("f 1 2\n", "f 1/9/1 2/1/1 3/1/1\n", "f 1 2 x\n"):
+        _write(d, "bad", std.split("usemtl")[0] + "usemtl grey\n" + bad)
+        with pytest.raises(mcpt.McptError):
+            mcpt.Scene(d, "bad", load_flags=mcpt.LOAD_STANDARD_OBJ)
+
+
+def test_mtllib_is_honoured_only_on_request(mcpt, tmp_path):
+    d = str(tmp_path) + os.sep
+    obj = "mtllib one.mtl two.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nusemtl red\nf 1/1/1 2/1/1 3/1/1\nusemtl lamp\nf 1/1/1 3/1/1 2/1/1\n"
+    _write(d, "m", obj, mtl="newmtl red\nKd 0.25 0.25 0.25\nnewmtl lamp\nKd 0 0 0\n")       # m.mtl: what the reference would read
+    open(d + "one.mtl", "w").write("newmtl red\nKd 1 0 0\nKs 0 0 0\n")
+    open(d + "two.mtl", "w").write("newmtl lamp\nKd 0 0 0\nKs 0 0 0\n")
+    plain = mcpt.Scene(d, "m")
+    libs = mcpt.Scene(d, "m", load_flags=mcpt.LOAD_MTLLIB)
+    assert plain.material(0)[0] == "red" and tuple(plain.material(0)[1][:3]) == (0.25, 0.25, 0.25)
+    assert libs.material(0)[0] == "red" and tuple(libs.material(0)[1][:3]) == (1.0, 0.0, 0.0)
+    os.remove(d + "two.mtl")
+    with pytest.raises(mcpt.McptError):
+        mcpt.Scene(d, "m", load_flags=mcpt.LOAD_MTLLIB)
+    with pytest.raises(mcpt.McptError):
+        mcpt.Scene(d, "m", load_flags=64)
+
+
+def test_morton_domain_from_bounds(mcpt):
+    """veach-mis spans [-10.5, 10.5]^3: 59 % of its face centres lie outside the reference's fixed [-1,4]^3 key domain and
+    are clamped to its border on at least one axis.  Keys on the scene's own bounds clamp none; faces, materials and the
+    BVH's shape are untouched, the leaf order is a permutation sorted by the new keys, and the root box is the same box."""
+    a = mcpt.Scene(SCENES, "veach-mis")
+    b = mcpt.Scene(SCENES, "veach-mis", load_flags=mcpt.LOAD_MORTON_BOUNDS)
+    ga, ma, ka = a.faces()
+    gb, mb, kb = b.faces()
+    assert np.array_equal(ga, gb) and np.array_equal(ma, mb)
+
+    def axes(k):        # undo the bit interleave: 10 bits per axis
+        out = np.zeros((k.shape[0], 3), dtype=np.uint32)
+        for bit in range(10):
+            for a, sh in enumerate((2, 1, 0)):
+                out[:, a] |= ((k >> (3 * bit + sh)) & 1) << bit
+        return out
+    on_border = lambda k: ((axes(k) == 0) | (axes(k) == 1023)).any(axis=1).mean()
+    assert on_border(ka) > 0.5 and on_border(kb) < 0.05
+    ob = b.leaf_order()
+    assert np.array_equal(np.sort(ob), np.arange(ga.shape[0]))
+    assert np.all(np.diff(kb[ob].astype(np.int64)) >= 0)
+    ia, ib = a.info.bvh, b.info.bvh
+    assert (ia.Nr, ia.Level, ia.Lv) == (ib.Nr, ib.Level, ib.Lv)
+    assert np.array_equal(a.bvh_nodes()[0][0], b.bvh_nodes()[0][0])
+    # the key itself: centre normalised to the bounds, 10 bits per axis, x most significant
+    v = gb[:, :9].reshape(-1, 3, 3)
+    lo = v.reshape(-1, 3).min(axis=0).astype(np.float32)
+    span = v.reshape(-1, 3).max(axis=0).astype(np.float32) - lo
+    c = (((v[:, 0] + v[:, 1]) + v[:, 2]) / 3).astype(np.float32)
+    q = np.clip((c - lo) / span * np.float32(1024), 0, 1023).astype(np.uint32)
+
+    def spread(x):
+        out = np.zeros_like(x)
+        for bit in range(10):
+            out |= ((x >> bit) & 1) << (3 * bit)
+        return out
+    assert np.array_equal(spread(q[:, 0]) * 4 + spread(q[:, 1]) * 2 + spread(q[:, 2]), kb)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 2), (64, 48), (7, 301)])
+def test_compressed_png_decodes_to_the_same_pixels(mcpt, shape):
+    from PIL import Image
+    h, w = shape
+    rng = np.random.default_rng(w * 1000 + h)
+    img = (rng.random((h, w, 3)) ** 3 * 255).astype(np.uint8)
+    img[h // 4: h // 2, w // 4: w // 2] = (200, 30, 30)             # a flat patch and a ramp: matches and filters get used
+    img[h // 2:, :, 1] = np.linspace(0, 255, w).astype(np.uint8)[None, :]
+    blob = mcpt.png_bytes_deflate(img)
+    assert np.array_equal(np.array(Image.open(io.BytesIO(blob)).convert("RGB")), img)
+    # structure by hand: signature, IHDR, one IDAT holding a valid zlib stream of h filtered scanlines, IEND
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(blob):
+        n, tag = struct.unpack(">I4s", blob[pos:pos + 8])
+        body = blob[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", blob[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body)
+        chunks.append((tag, body))
+        pos += 12 + n
+    assert [t for t, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+    assert len(zlib.decompress(chunks[1][1])) == h * (3 * w + 1)
+    if h * w > 1000:
+        assert len(blob) < len(mcpt.png_bytes(img))
+
+
+def test_pfm_holds_the_linear_frame(mcpt, tmp_path):
+    rng = np.random.default_rng(3)
+    img = rng.random((5, 7, 3)) * 40 - 1          # beyond [0,1]: no clamp
+    f = str(tmp_path / "a.pfm")
+    mcpt.write_pfm(f, img)
+    raw = open(f, "rb").read()
+    head = b"PF\n7 5\n-1.0\n"
+    assert raw.startswith(head)
+    back = np.frombuffer(raw[len(head):], dtype="<f4").reshape(5, 7, 3)[::-1]
+    assert np.array_equal(back, img.astype(np.float32))
+
+
+def test_checkpoint_round_trip_and_mismatch(mcpt, tmp_path):
+    sc = mcpt.Scene(SCENES, "cornell-box", width=16, height=12)
+    rng = np.random.default_rng(4)
+    img = rng.random((12, 16, 3))
+    done = np.array([1, 0, 1, 0, 0], dtype=np.uint8)
+    f = str(tmp_path / "frame.ckp")
+    with pytest.raises(mcpt.McptError) as e:
+        mcpt.checkpoint_load(f, sc, 8, 5, 5)
+    assert e.value.code == -1                                            # MCPT_ERR_IO: no checkpoint yet
+    mcpt.checkpoint_save(f, sc, img, 8, 5, done)
+    assert not os.path.exists(f + ".tmp")
+    back, d2 = mcpt.checkpoint_load(f, sc, 8, 5, 5)
+    assert np.array_equal(back.view(np.uint64), img.view(np.uint64)) and np.array_equal(d2, done)
+    for spp, seed, parts in ((9, 5, 5), (8, 6, 5), (8, 5, 4)):
+        with pytest.raises(mcpt.McptError) as e:
+            mcpt.checkpoint_load(f, sc, spp, seed, parts)
+        assert e.value.code == -2                                        # MCPT_ERR_PARSE: another frame's checkpoint
+    other = mcpt.Scene(SCENES, "veach-mis", width=16, height=12)
+    with pytest.raises(mcpt.McptError):
+        mcpt.checkpoint_load(f, other, 8, 5, 5)
