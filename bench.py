@@ -235,13 +235,13 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload (bench.py cannot collect PMC itself)
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
-        if args.scene == "cornell-box" and (args.width, args.height, args.spp) == (1280, 720, 256) and world == 1 and os.path.exists(tf):
+        if args.scene == "cornell-box" and (args.width, args.height, args.spp) == (1280, 720, 256) and world == 1 and args.sim_world <= 1 and os.path.exists(tf):
             tj = json.load(open(tf))
             traffic, traffic_src = tj["bytes_per_launch"], "profiles/r01_final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         avg_ms = tot["ms_trace"] / n_launch
         achieved = (alg_bytes_rank0 / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
-            "metric": "Mrays/s on cornell-box 1280x720 SPP=256 (closest-hit queries actually traced / wall time incl. gather)",
+            "metric": "Mrays/s on %s %dx%d SPP=%d (closest-hit queries actually traced / wall time incl. gather)" % (args.scene, args.width, args.height, args.spp),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec_per_frame * 1e3, "sec_per_frame": sec_per_frame, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64",

@@ -91,7 +91,7 @@ struct mcpt_device {
     TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
     long long* slow_list = nullptr;
     unsigned int slow_cap = 1u << 20;
-    long long finish_threshold = 200000;            // paths left at which the finishing pass takes over (MCPT_FINISH_PATHS)
+    long long finish_threshold = 500000;            // paths left at which the finishing pass takes over (MCPT_FINISH_PATHS; sweep: flat from 2e5 to 1e6)
 };
 
 extern "C" {

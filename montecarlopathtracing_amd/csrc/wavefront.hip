@@ -7,6 +7,7 @@
 #include "shade_common.hpp"
 #include "shade_path.hpp"
 #include "trace_persistent.hpp"
+#include "vertex.hpp"
 #include "wavefront.hpp"
 
 namespace mcpt {
@@ -159,23 +160,10 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         if (!alive) continue;
         const long long j = off;
 
-        // ---- shade vertex `depth` at position j (pathTracing.cpp:147-241)
-        const DTri* tr = S.tris + leaf;
-        const DMaterial* m = S.materials + tr->material;
-        const DTriShade* sh = S.shade + leaf;
-        const V3 g = barycentric_s(ld3(tr->v1), ld3(tr->v2), ld3(tr->v3), p);
-        const V3 pn = (ld3(sh->vn1) * g.x + ld3(sh->vn2) * g.y) + ld3(sh->vn3) * g.z;
-        V3 kd;
-        if (m->has_map) {
-            const double row = sh->vt1[0] * g.x + sh->vt2[0] * g.y + sh->vt3[0] * g.z;
-            const double col = sh->vt1[1] * g.x + sh->vt2[1] * g.y + sh->vt3[1] * g.z;
-            const double irow = row - floor(row), icol = col - floor(col);
-            int rr = (int)(irow * m->map_h), cc = (int)(icol * m->map_w);
-            rr = rr < 0 ? 0 : (rr > m->map_h - 1 ? m->map_h - 1 : rr);
-            cc = cc < 0 ? 0 : (cc > m->map_w - 1 ? m->map_w - 1 : cc);
-            const uint8_t* px = S.texels + m->tex_offset + ((size_t)rr * m->map_w + cc) * 3;
-            kd = mk((double)px[2] * MCPT_INV_255, (double)px[1] * MCPT_INV_255, (double)px[0] * MCPT_INV_255);
-        } else kd = ld3(m->kd);
+        // ---- shade vertex `depth` at position j (pathTracing.cpp:147-241; the pieces are in vertex.hpp)
+        const DMaterial* m = S.materials + S.tris[leaf].material;
+        V3 pn, kd;
+        vertex_surface(S, leaf, p, m, pn, kd);
 
         const int slot = a.first_slot + id / a.spp;
         RngKey key;
@@ -184,89 +172,20 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
 
         int sample_mat = -1;
         for (int l = 0; l < nl; l++) {
-            const DLight* lt = S.lights + l;
-            V3 xl = mk(0, 0, 0), vn = mk(0, 0, 0);
-            double u0, u1, u2, u3;
-            uniform2(key, depth, 2u * l, u0, u1);
-            const double rnd = u0 * S.area0;
-            const int jt = pick_light_triangle(S.light_cdf + lt->first, lt->ntri, lt->cdf_sorted != 0, rnd);
-            if (jt >= 0) {
-                uniform2(key, depth, 2u * l + 1u, u2, u3);
-                const DLightTri* q = S.light_tris + lt->first + jt;
-                sample_mat = lt->material;
-                const double isum = frcp(u1 + u2 + u3);
-                const double p1 = u1 * isum, p2 = u2 * isum, p3 = u3 * isum;
-                xl = (ld3(q->v1) * p1 + ld3(q->v2) * p2) + ld3(q->v3) * p3;
-                vn = (ld3(q->vn1) * p1 + ld3(q->vn2) * p2) + ld3(q->vn3) * p3;
-            }
-            const V3 direction = normalized_s(xl - p);
-            const double kd_dots = dot(direction, pn);
-            int expect = -2;
-            if (kd_dots > 0) {                                                   // the only case in which the shadow ray's answer is used
-                                const double cos_theta = fabs(dot(direction, vn) * frcp(norm(direction)) * frcp(norm(vn)));
-                const double cos_theta_hat = fabs(dot(direction, pn) * frcp(norm(direction)) * frcp(norm(pn)));
-                const double dd = norm(xl - p);
-                const double dist = (1.0 < dd) ? dd : 1.0;
-                const V3 intensity = ((ld3(lt->radiance) * cos_theta) * cos_theta_hat) * (frcp(sqr(dist)) * lt->total_area);
-                const V3 c = mk(kd.x * intensity.x * kd_dots * MCPT_INV_PI, kd.y * intensity.y * kd_dots * MCPT_INV_PI, kd.z * intensity.z * kd_dots * MCPT_INV_PI);
+            V3 direction, c;
+            const int expect = light_sample(S, key, depth, l, p, pn, kd, sample_mat, direction, c);
+            if (expect != -2) {
                 stc(a.out.c + (long long)l * 3 * cap, cap, j, folded ? mk(T.x * c.x, T.y * c.y, T.z * c.z) : c);
                 stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);       // origin p + direction * 0.01: WfRaySource
-                expect = sample_mat;
                 ls.shadow++;
             } else ls.skipped++;
             a.out.expect[(long long)l * cap + j] = expect;
         }
 
         if (!FIRST) stc(a.rays.p, cap, j, p);            // first pass: the pixel's primary hit, read from a.hits where needed
-        int btype = -1, at_vertex = 0;
-        V3 wgt = mk(1, 1, 1);
-        if (depth + 1 < MCPT_MAX_DEPTH_DEV) {
-            double u_rr, u_fresnel;
-            uniform2(key, depth, 2u * nl, u_rr, u_fresnel);
-            if (u_rr < MCPT_P_RR) {
-                V3 nd = mk(0, 0, 0);
-                const V3 ks = ld3(m->ks);
-                if (m->Ni > 1) {
-                    double n1, n2;
-                    const double cos_in = dot(neg(dir), pn);
-                    V3 normal;
-                    if (cos_in > 0) { normal = neg(pn); n1 = m->Ni; n2 = 1.0; }
-                    else { normal = pn; n1 = 1.0; n2 = m->Ni; }
-                    const double rf0 = sqr((n1 - n2) / (n1 + n2));
-                    const double fresnel = rf0 + (1.0f - rf0) * pow5(1.0f - fabs(cos_in));
-                    if (fresnel < u_fresnel) {
-                        V3 direction;
-                        at_vertex = MCPT_BT_NO_OFFSET;
-                        if (refract_dir(neg(dir), normal, n1 / n2, direction)) { nd = direction; btype = RT_TRANSMISSION; }
-                        else {
-                            const V3 incoming = neg(dir);
-                            nd = incoming - (normal * dot(incoming, normal)) * 2; btype = RT_SPECULAR;
-                        }
-                    }
-                }
-                if (btype < 0) {
-                    double u_lobe, u_phi, u_theta, unused;
-                    uniform2(key, depth, 2u * nl + 1u, u_lobe, u_phi);
-                    uniform2(key, depth, 2u * nl + 2u, u_theta, unused);
-                    const double kd_norm = norm(kd), ks_norm = norm(ks);
-                    V3 direction;
-                    if (ks_norm != 0 && kd_norm / ks_norm < u_lobe) {
-                        const V3 incoming = neg(dir);
-                        const V3 reflect = incoming - (pn * dot(incoming, pn)) * 2;
-                        direction = brdf_sample(u_phi, u_theta, reflect, RT_SPECULAR, m->Ns);
-                        btype = RT_SPECULAR;
-                    } else {
-                        direction = brdf_sample(u_phi, u_theta, pn, RT_DIFFUSE, m->Ns);
-                        btype = RT_DIFFUSE;
-                    }
-                    nd = direction;                                              // origin p + direction * 0.01
-                }
-                wgt = btype == RT_DIFFUSE ? kd : (btype == RT_SPECULAR ? ks : mk(1, 1, 1));
-                stc(a.out.bdir, cap, j, nd);
-                btype |= at_vertex;
-                ls.bounce++;
-            }
-        }
+        V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
+        const int btype = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
+        if (btype >= 0) { stc(a.out.bdir, cap, j, nd); ls.bounce++; }
         a.out.id[j] = id;
         a.out.btype[j] = btype;
         if (folded) stc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
@@ -392,9 +311,13 @@ __global__ void __launch_bounds__(256) k_wf_trace_reference(DScene S, WfArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------- finishing pass
-// When only a few thousand paths are left, a launch pair per bounce costs more than the paths: every remaining path is run
-// to its end by one lane.  Input = the state logic(depth) has just written (its rays not yet traced): trace them, resolve the
-// vertex exactly as the next logic pass would, then continue with the shared path loop (shade_path_from).
+// When few paths are left, a launch pair per bounce costs more than the paths: every launch starts with cold caches and runs at
+// memory latency.  One persistent launch takes over the state logic(depth) has just written (its rays not yet traced) and runs
+// every remaining path to its end.  A wave advances its 64 paths one vertex per iteration, in step: trace the shadow rays,
+// resolve, trace the bounce ray, shade the next vertex (vertex.hpp: the arithmetic of k_wf_logic).  Lanes whose path has ended
+// take the next unclaimed path (one atomic per refill on the pass's own count slot), so a wave is as long as its share of
+// the work, not as its longest path.  A lane that has just adopted a path finds the rays of its first step in the wavefront
+// state instead of computing them; from the second step on everything lives in registers.
 __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
 {
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
@@ -402,53 +325,120 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
     if (n > (long long)a.finish_below) return;                         // still wavefront work
     const long long cap = a.cap;
     const int nl = a.nl;
+    const bool folded = nl == 1;                                       // see k_wf_logic
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     LaneStats ls;
     Work w = {0, 0};
     int* stack = lds_stack + threadIdx.x;
-    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
-        const int id = a.out.id[j];
-        const bool folded = nl == 1;                     // see k_wf_logic
-        V3 T = mk(1, 1, 1), L = mk(0, 0, 0);
-        if (a.depth > 0 || folded) T = ldc(a.out.T, cap, j);
-        if (a.depth > 0) L = ldc(a.out.L, cap, j);
-        WfRaySource src; src.a = a; src.n_paths = n;
-        const V3 p = src.vertex(j);
-        V3 L_dir = mk(0, 0, 0);
-        for (int l = 0; l < nl; l++) {
-            const int expect = a.out.expect[(long long)l * cap + j];
-            if (expect == -2) continue;
-            Ray r;
-            r.d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j);
-            r.o = p + r.d * 0.01;
-            Hit h;
-            const bool ok = trace_lane_fast(S, r, h, w, stack, 256);
-            const bool vis = (ok ? S.tris[h.leaf].material : -1) == expect;
-            const V3 c = ldc(a.out.c + (long long)l * 3 * cap, cap, j);
-            L_dir.x += vis ? c.x : c.x * 0.0;
-            L_dir.y += vis ? c.y : c.y * 0.0;
-            L_dir.z += vis ? c.z : c.z * 0.0;
-        }
-        L = folded ? L + L_dir : L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
-        double out[3] = {L.x, L.y, L.z};
-        const int bt = a.out.btype[j];
-        if (bt >= 0) {
-            Ray r;
-            r.d = ldc(a.out.bdir, cap, j);
-            r.o = (bt & MCPT_BT_NO_OFFSET) ? p : p + r.d * 0.01;
-            Hit h;
-            if (trace_lane_fast(S, r, h, w, stack, 256)) {
-                if (!folded) {
-                    const V3 wgt = ldc(a.out.w, cap, j);
-                    T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
-                }
+    WfRaySource src; src.a = a; src.n_paths = n;
+    bool queue_empty = false;
+
+    enum { M_IDLE = 0, M_ADOPTED = 1, M_VERTEX = 2 };
+    int mode = M_IDLE;
+    long long j = 0;                    // M_ADOPTED: position in the wavefront state
+    int id = 0, leaf = -1, in_type = RT_TRANSMISSION;
+    uint32_t depth = 0;                 // M_ADOPTED: vertex whose rays are pending; M_VERTEX: vertex about to be shaded
+    V3 T = mk(1, 1, 1), L = mk(0, 0, 0), dir = mk(0, 0, 0), p = mk(0, 0, 0);
+    RngKey key;
+    key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32); key.pixel = 0; key.sample = 0;
+
+    for (;;) {
+        // ---- idle lanes adopt the next paths
+        const unsigned long long idle = __ballot(mode == M_IDLE);
+        if (idle && !queue_empty && (__popcll(idle) >= 16 || idle == ~0ull)) {
+            const unsigned int want = (unsigned int)__popcll(idle);
+            unsigned int got = 0;
+            if (lane == 0) got = atomicAdd(&a.counts->pad[0], want);
+            got = __shfl(got, 0, 64);
+            if ((long long)got + want >= n) queue_empty = true;
+            const long long mine = (long long)got + __popcll(idle & lt_mask);
+            if (mode == M_IDLE && mine < n) {
+                mode = M_ADOPTED; j = mine;
+                id = a.out.id[j];
+                depth = (uint32_t)a.depth;
+                T = mk(1, 1, 1); L = mk(0, 0, 0);
+                if (a.depth > 0 || folded) T = ldc(a.out.T, cap, j);
+                if (a.depth > 0) L = ldc(a.out.L, cap, j);
+                p = src.vertex(j);
                 const int slot = a.first_slot + id / a.spp;
-                RngKey key;
-                key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
                 key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); key.sample = (uint32_t)(id % a.spp);
-                shade_path_from<true>(S, key, (uint32_t)a.depth + 1u, T, L, neg(r.d), bt & 7, h, out, ls, stack, 256);
             }
         }
-        a.rad[(size_t)id * 3] = out[0]; a.rad[(size_t)id * 3 + 1] = out[1]; a.rad[(size_t)id * 3 + 2] = out[2];
+        if (!__ballot(mode != M_IDLE)) {
+            if (queue_empty) break;
+            continue;
+        }
+
+        // ---- lanes at a vertex: emitter test, surface (pathTracing.cpp:141-160)
+        const DMaterial* m = nullptr;
+        V3 pn = mk(0, 0, 0), kd = mk(0, 0, 0);
+        bool ended = false;
+        if (mode == M_VERTEX) {
+            ls.shades++;
+            if (depth > ls.depth) ls.depth = depth;
+            m = S.materials + S.tris[leaf].material;
+            if (m->light >= 0) {
+                const V3 rad = ld3(S.lights[m->light].radiance);
+                if (depth == 0) L = rad;
+                else if (in_type != RT_DIFFUSE) L = L + mk(T.x * rad.x, T.y * rad.y, T.z * rad.z);
+                ended = true;
+            } else vertex_surface(S, leaf, p, m, pn, kd);
+        }
+
+        // ---- direct light: one shadow ray per light, traced by all lanes together
+        V3 L_dir = mk(0, 0, 0);
+        int sample_mat = -1;
+        for (int l = 0; l < nl; l++) {
+            int expect = -2;
+            V3 c = mk(0, 0, 0);
+            Ray r; r.o = p; r.d = mk(1, 1, 1);
+            if (mode == M_VERTEX && !ended) {
+                expect = light_sample(S, key, depth, l, p, pn, kd, sample_mat, r.d, c);
+                if (expect != -2) ls.shadow++; else ls.skipped++;
+            } else if (mode == M_ADOPTED) {
+                expect = a.out.expect[(long long)l * cap + j];
+                if (expect != -2) { c = ldc(a.out.c + (long long)l * 3 * cap, cap, j); r.d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j); }
+            }
+            if (expect != -2) {
+                r.o = p + r.d * 0.01;
+                Hit h;
+                const bool ok = trace_lane_fast(S, r, h, w, stack, 256);
+                const bool vis = (ok ? S.tris[h.leaf].material : -1) == expect;
+                L_dir.x += vis ? c.x : c.x * 0.0;
+                L_dir.y += vis ? c.y : c.y * 0.0;
+                L_dir.z += vis ? c.z : c.z * 0.0;
+            }
+        }
+        if (mode == M_ADOPTED && folded) L = L + L_dir;                 // its c was stored as T * c
+        else L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
+
+        // ---- bounce: Russian roulette + nextRay (or the stored ray), closest hit, next vertex
+        int bt = -1;
+        V3 wgt = mk(1, 1, 1);
+        Ray br; br.o = p; br.d = mk(1, 1, 1);
+        if (mode == M_VERTEX && !ended) {
+            bt = bounce_sample(key, depth, nl, m, dir, pn, kd, br.d, wgt);
+            if (bt >= 0) ls.bounce++;
+        } else if (mode == M_ADOPTED) {
+            bt = a.out.btype[j];
+            if (bt >= 0) { br.d = ldc(a.out.bdir, cap, j); if (!folded) wgt = ldc(a.out.w, cap, j); }
+        }
+        bool goes_on = false;
+        if (bt >= 0) {
+            if (!(bt & MCPT_BT_NO_OFFSET)) br.o = p + br.d * 0.01;
+            Hit h;
+            if (trace_lane_fast(S, br, h, w, stack, 256)) {
+                // an adopted path with one light already holds the throughput after its bounce
+                if (!(mode == M_ADOPTED && folded)) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
+                leaf = h.leaf; p = h.p; dir = neg(br.d); in_type = bt & 7; depth++;
+                goes_on = true;
+            }
+        }
+        if (mode != M_IDLE) {
+            if (goes_on) mode = M_VERTEX;
+            else { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; mode = M_IDLE; }
+        }
     }
     ls.nodes += w.nodes; ls.tris += w.tris;
     flush_stats(a.ctr, ls);
@@ -550,7 +540,9 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
 void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st)
 {
     if (n_upper <= 0) return;
-    hipLaunchKernelGGL(k_wf_finish, dim3(grid_for(n_upper, 256, 1024)), dim3(256), 0, st, S, a);
+    static unsigned resident = 0;
+    if (!resident) resident = unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_finish)));
+    hipLaunchKernelGGL(k_wf_finish, dim3(grid_for(n_upper, 256, resident)), dim3(256), 0, st, S, a);
 }
 
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)

@@ -39,7 +39,6 @@ struct WfRays {
     double* p;              // [3][cap]     the shaded vertex
     double* d;              // [nl][3][cap] shadow-ray directions
 };
-#define MCPT_BT_NO_OFFSET 8
 
 struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
     unsigned long long head;        // next unclaimed ray slot
