@@ -84,6 +84,7 @@ struct mcpt_device {
     size_t sample_budget_bytes = size_t(4) << 30;   // megakernel path: radiance staging buffer per chunk
     // wavefront workspace
     size_t wf_budget_bytes = 0;                     // path state + rays; 0 = half of the free HBM (MCPT_WORKSPACE_GB overrides)
+    size_t wf_auto_budget = 0;                      // that half, asked for once (hipMemGetInfo costs a few hundred microseconds)
     void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
     int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
     WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
@@ -775,9 +776,12 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
     // the HBM that is free, which holds a whole 1280x720 SPP-256 frame (83 GB) on a 288-GB device.
     size_t budget = d->wf_budget_bytes;
     if (!budget) {
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        budget = std::max<size_t>((free_b + d->wf_ws_bytes + d->rad_cap) / 2, size_t(1) << 30);
+        if (!d->wf_auto_budget) {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            d->wf_auto_budget = std::max<size_t>((free_b + d->wf_ws_bytes + d->rad_cap) / 2, size_t(1) << 30);
+        }
+        budget = d->wf_auto_budget;
     }
     int64_t cap = int64_t((budget - overhead) / (bpp + 24));      // + 24 B radiance per sample
     cap = std::min<int64_t>(cap, npx * int64_t(spp));

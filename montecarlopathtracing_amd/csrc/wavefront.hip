@@ -5,7 +5,6 @@
 
 #include "dev_common.hpp"
 #include "shade_common.hpp"
-#include "shade_path.hpp"
 #include "trace_persistent.hpp"
 #include "vertex.hpp"
 #include "wavefront.hpp"
@@ -322,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
 {
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     const long long n = a.counts->n_next;
-    if (n > (long long)a.finish_below) return;                         // still wavefront work
+    if (n == 0 || n > (long long)a.finish_below) return;               // nothing left, or still wavefront work
     const long long cap = a.cap;
     const int nl = a.nl;
     const bool folded = nl == 1;                                       // see k_wf_logic
