@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-png", default=None)
     ap.add_argument("--tris", type=int, default=10_000_000, help="--scene synthetic: number of lattice triangles")
+    ap.add_argument("--build", default="default", choices=["default", "host", "device", "device_fast"],
+                    help="where the BVHs are built (mcpt_device_create_ex); device_fast: the fast walk's hierarchy on the GPU too")
     ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: render only rank 0's tiles of an N-rank partition on this GPU")
     args = ap.parse_args()
 
@@ -154,12 +156,13 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
 
+    build_mode = {"default": None, "host": M.BUILD_HOST, "device": M.BUILD_DEVICE, "device_fast": M.BUILD_DEVICE_FAST}[args.build]
     if args.scene == "synthetic":
         from montecarlopathtracing_amd import synthetic
         t_gen = time.perf_counter()
         scene = synthetic.make_scene(M, args.tris, defer_build=True, width=args.width, height=args.height)
         t_dev = time.perf_counter()
-        dev = M.Device(scene, local_rank)          # Morton + sort + BVH levels on the GPU, SAH hierarchy on the host
+        dev = M.Device(scene, local_rank, build=build_mode)   # Morton + sort + BVH levels on the GPU; fast hierarchy: host SAH or GPU (--build device_fast)
         if rank == 0:
             print("synthetic scene: %d triangles, generate+create %.1f s, device build %.1f s" %
                   (scene.info.num_faces, t_dev - t_gen, time.perf_counter() - t_dev), file=sys.stderr)
@@ -170,11 +173,11 @@ def main():
         scene_dir = tempfile.mkdtemp(prefix="mcpt_interior_") + os.sep
         synthetic.write_interior(scene_dir, "interior", width=args.width, height=args.height)
         scene = M.Scene(scene_dir, "interior")
-        dev = M.Device(scene, local_rank)
+        dev = M.Device(scene, local_rank, build=build_mode)
     else:
         scene_dir = write_scene_dir(args.scene, args.width, args.height)
         scene = M.Scene(scene_dir, args.scene)
-        dev = M.Device(scene, local_rank)
+        dev = M.Device(scene, local_rank, build=build_mode)
     rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev, stage_on_cpu=share_gpu)
     if args.sim_world > 1:          # one rank's share of an N-way partition, no communication
         class _Sim:

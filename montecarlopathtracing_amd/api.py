@@ -12,7 +12,7 @@ TRACE_FAST, TRACE_REFERENCE = 0, 1
 RENDER_DEFAULT, RENDER_MEGAKERNEL = 0, 2
 LOAD_STANDARD_OBJ, LOAD_MTLLIB, LOAD_MORTON_BOUNDS = 1, 2, 4
 OUT_PNG_DEFLATE, OUT_PFM = 1, 2
-BUILD_HOST, BUILD_DEVICE = 0, 1
+BUILD_HOST, BUILD_DEVICE, BUILD_DEVICE_FAST = 0, 1, 2
 SCENE_DEFER_BUILD = 1
 
 

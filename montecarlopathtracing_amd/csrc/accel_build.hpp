@@ -9,7 +9,7 @@
 namespace mcpt {
 
 #ifndef MCPT_FAST_STACK
-#define MCPT_FAST_STACK 32
+#define MCPT_FAST_STACK 36
 #endif
 constexpr int kFastMaxDepth = MCPT_FAST_STACK;          // inner levels; bounds the per-lane LDS stack
 constexpr int kFastMaxLeaf = 4;            // most triangles a leaf may hold (3 bits of the reference; bit 3 is a runtime flag)

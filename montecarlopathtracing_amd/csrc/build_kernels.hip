@@ -3,6 +3,8 @@
 // complete tree (MTPC/BVH.cpp:56-124), written straight into the records the walk kernels read.  Results are
 // bit-identical to the host build (bvh_build.cpp); tests compare them node for node.
 #include <hip/hip_runtime.h>
+
+#include <cstring>
 #include <hipcub/hipcub.hpp>
 
 #include "build_kernels.hpp"
@@ -96,6 +98,185 @@ __global__ void k_gather_tris(const DTri* __restrict__ tris, const int32_t* __re
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = tris[slots[i]];
 }
+
+// ---------------------------------------------------------------------------------------------- fast hierarchy on the device
+struct FBox { double lo[3], hi[3]; };
+
+// The fast hierarchy keeps its own order: 63-bit Morton codes (21 bits per axis) of the triangle centres on the scene's bounding
+// box.  The reference's 30-bit keys on the fixed [-1,4]^3 cube leave thousands of triangles of a large scene on one key, in
+// .obj order -- groups of four of those make useless leaves (measured: 174 triangle tests per ray on the 10 M-triangle scene).
+__device__ __forceinline__ unsigned long long spread21(unsigned long long x)
+{
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+struct FastDomain { double lo[3], inv[3]; };
+__global__ void k_fast_keys(const DTri* __restrict__ tris, int t, FastDomain dom, unsigned long long* __restrict__ keys, int32_t* __restrict__ idx)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= t) return;
+    const DTri* tr = tris + k;
+    unsigned long long key = 0;
+    for (int a = 0; a < 3; a++) {
+        const double c = (tr->v1[a] + tr->v2[a] + tr->v3[a]) * (1.0 / 3.0);
+        double u = (c - dom.lo[a]) * dom.inv[a] * 2097152.0;
+        u = u >= 0.0 ? u : 0.0;                   // NaN -> 0
+        u = u <= 2097151.0 ? u : 2097151.0;
+        key |= spread21((unsigned long long)u) << (2 - a);
+    }
+    keys[k] = key; idx[k] = k;
+}
+
+// box of fast leaf g = triangles 4g .. 4g+3 of the sorted copy (each triangle's own box is the reference's, BVH.cpp:87-97)
+__global__ void k_fast_leaf_boxes(const DTri* __restrict__ tris, int t, int groups, FBox* __restrict__ boxes, unsigned long long* __restrict__ absmax_bits)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    double am = 0.0;
+    if (g < groups) {
+        FBox b;
+        for (int a = 0; a < 3; a++) { b.lo[a] = __builtin_inf(); b.hi[a] = -__builtin_inf(); }
+        const int first = 4 * g, end = first + 4 < t ? first + 4 : t;
+        for (int k = first; k < end; k++) {
+            const DTri* tr = tris + k;
+            for (int a = 0; a < 3; a++) {
+                const double lo = fmin(fmin(tr->v1[a], tr->v2[a]), tr->v3[a]), hi = fmax(fmax(tr->v1[a], tr->v2[a]), tr->v3[a]);
+                b.lo[a] = fmin(b.lo[a], lo); b.hi[a] = fmax(b.hi[a], hi);
+                if (isfinite(lo)) am = fmax(am, fabs(lo));
+                if (isfinite(hi)) am = fmax(am, fabs(hi));
+            }
+        }
+        boxes[g] = b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmax(am, __shfl_down(am, off, 64));
+    if ((threadIdx.x & 63) == 0 && am > 0.0) atomicMax(absmax_bits, (unsigned long long)__double_as_longlong(am));   // non-negative doubles order like integers
+}
+
+// One level: node i takes children 4i .. 4i+3 of the level below (nodes, or fast leaves when leaf_level), stores its own exact
+// box for the level above and its compressed record: per axis a grid origin p (fp32, rounded down), a power-of-two step and the
+// children's planes as 8-bit offsets rounded outward, verified in fp64 (the same rule as the host builder, accel_build.cpp).
+__global__ void k_fast_level(const FBox* __restrict__ child_boxes, int n_children, int child_base, int leaf_level, int t,
+                             FBox* __restrict__ my_boxes, CwNode* __restrict__ nodes, int node_base, int n_nodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    FBox kid[4];
+    int nk = 0;
+    for (int c = 0; c < 4; c++) if (4 * i + c < n_children) kid[nk++] = child_boxes[4 * i + c];
+    FBox own;
+    for (int a = 0; a < 3; a++) {
+        own.lo[a] = __builtin_inf(); own.hi[a] = -__builtin_inf();
+        for (int c = 0; c < nk; c++) { own.lo[a] = fmin(own.lo[a], kid[c].lo[a]); own.hi[a] = fmax(own.hi[a], kid[c].hi[a]); }
+    }
+    my_boxes[i] = own;
+    CwNode nd;
+    nd.nchild = (uint8_t)nk;
+    nd.pad[0] = nd.pad[1] = 0;
+    for (int a = 0; a < 3; a++) {
+        const float pf = __double2float_rd(own.lo[a]);
+        const double p = (double)pf;
+        int e = -126;
+        const double ext = own.hi[a] - p;
+        if (ext > 0) { const int want = (int)ceil(log2(ext / 255.0)); e = want > -126 ? want : -126; }
+        uint32_t wlo = 0, whi = 0;
+        for (;; e++) {
+            const double sc = ldexp(1.0, e);
+            bool ok = p + 255.0 * sc >= own.hi[a];
+            wlo = 0; whi = 0;
+            for (int c = 0; ok && c < nk; c++) {
+                double ql = floor((kid[c].lo[a] - p) / sc), qh = ceil((kid[c].hi[a] - p) / sc);
+                ql = fmin(fmax(ql, 0.0), 255.0); qh = fmin(fmax(qh, 0.0), 255.0);
+                while (ql > 0 && p + ql * sc > kid[c].lo[a]) ql -= 1;
+                while (qh < 255 && p + qh * sc < kid[c].hi[a]) qh += 1;
+                if (p + ql * sc > kid[c].lo[a] || p + qh * sc < kid[c].hi[a]) ok = false;
+                wlo |= (uint32_t)ql << (8 * c); whi |= (uint32_t)qh << (8 * c);
+            }
+            if (ok || e >= 127) break;          // e = 127 cannot fail for finite boxes; non-finite scenes never use this structure
+        }
+        nd.p[a] = pf; nd.e[a] = (int8_t)e; nd.qlo[a] = wlo; nd.qhi[a] = whi;
+    }
+    for (int c = 0; c < 4; c++) {
+        const int ci = 4 * i + c;
+        if (ci >= n_children) nd.child[c] = (int32_t)0x80000000;               // MCPT_FAST_EMPTY
+        else if (leaf_level) { const int first = 4 * ci, count = (first + 4 < t ? 4 : t - first); nd.child[c] = -1 - ((first << 4) | (count - 1)); }
+        else nd.child[c] = child_base + ci;
+    }
+    nodes[node_base + i] = nd;
+}
+
+hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], const double hi[3], CwNode** cw, DTri** fast_tris, int* n_nodes, int* levels,
+                             double* absmax, hipStream_t st)
+{
+    *cw = nullptr; *fast_tris = nullptr; *n_nodes = 0; *levels = 0; *absmax = 0;
+    if (t <= 0 || t > (1 << 27)) return hipErrorInvalidValue;                  // leaf references hold first << 4
+    // ---- order: sort (63-bit Morton code, leaf index), gather the triangle records into that order
+    DTri* tris = nullptr;
+    {
+        unsigned long long *keys = nullptr, *keys_out = nullptr;
+        int32_t *idx = nullptr, *idx_out = nullptr;
+        void* tmp = nullptr;
+        size_t tmp_bytes = 0;
+        auto drop = [&]() { (void)hipFree(keys); (void)hipFree(keys_out); (void)hipFree(idx); (void)hipFree(idx_out); (void)hipFree(tmp); };
+        hipError_t rc = hipMalloc(reinterpret_cast<void**>(&keys), size_t(t) * 8);
+        if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&keys_out), size_t(t) * 8);
+        if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&idx), size_t(t) * 4);
+        if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&idx_out), size_t(t) * 4);
+        if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&tris), size_t(t) * sizeof(DTri));
+        if (rc != hipSuccess) { drop(); (void)hipFree(tris); return rc; }
+        FastDomain dom;
+        for (int a = 0; a < 3; a++) { dom.lo[a] = lo[a]; const double ext = hi[a] - lo[a]; dom.inv[a] = ext > 0 ? 1.0 / ext : 0.0; }
+        hipLaunchKernelGGL(k_fast_keys, dim3((t + 255) / 256), dim3(256), 0, st, leaf_tris, t, dom, keys, idx);
+        rc = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st);
+        if (rc == hipSuccess) rc = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+        if (rc == hipSuccess) rc = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st);
+        if (rc == hipSuccess) { hipLaunchKernelGGL(k_gather_tris, dim3((t + 255) / 256), dim3(256), 0, st, leaf_tris, idx_out, t, tris); rc = hipGetLastError(); }
+        if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+        drop();
+        if (rc != hipSuccess) { (void)hipFree(tris); return rc; }
+    }
+    const int groups = (t + 3) / 4;
+    int size[16], L = 0;                                                       // size[d] = nodes of inner level d, bottom first
+    for (int n = groups;;) { n = (n + 3) / 4; size[L++] = n; if (n == 1) break; }
+    int total = 0;
+    for (int d = 0; d < L; d++) total += size[d];
+    FBox *a = nullptr, *b = nullptr;
+    unsigned long long* am = nullptr;
+    CwNode* nodes = nullptr;
+    auto cleanup = [&]() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(am); };
+    hipError_t rc = hipMalloc(reinterpret_cast<void**>(&a), size_t(groups) * sizeof(FBox));
+    if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&b), size_t(size[0]) * sizeof(FBox));
+    if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&am), sizeof(unsigned long long));
+    if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&nodes), size_t(total) * sizeof(CwNode));
+    if (rc == hipSuccess) rc = hipMemsetAsync(am, 0, sizeof(unsigned long long), st);
+    if (rc != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(tris); return rc; }
+    hipLaunchKernelGGL(k_fast_leaf_boxes, dim3((groups + 255) / 256), dim3(256), 0, st, tris, t, groups, a, am);
+    // root = node 0: level bases run top-down while the levels are built bottom-up
+    int n_children = groups;
+    for (int d = 0; d < L; d++) {
+        int base = 0, child_base = 0;
+        for (int u = L - 1; u > d; u--) base += size[u];
+        child_base = base + size[d];                                           // the level below follows this one
+        hipLaunchKernelGGL(k_fast_level, dim3((size[d] + 255) / 256), dim3(256), 0, st, a, n_children, child_base, d == 0 ? 1 : 0, t, b, nodes, base,
+                           size[d]);
+        FBox* tmp = a; a = b; b = tmp;                                         // b (size[0] entries) is large enough for every later level
+        n_children = size[d];
+    }
+    unsigned long long bits = 0;
+    rc = hipGetLastError();
+    if (rc == hipSuccess) rc = hipMemcpyAsync(&bits, am, sizeof bits, hipMemcpyDeviceToHost, st);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    cleanup();
+    if (rc != hipSuccess) { (void)hipFree(nodes); (void)hipFree(tris); return rc; }
+    double v; std::memcpy(&v, &bits, sizeof v);
+    *cw = nodes; *fast_tris = tris; *n_nodes = total; *levels = L; *absmax = v;
+    return hipSuccess;
+}
+
 
 #define BK_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 

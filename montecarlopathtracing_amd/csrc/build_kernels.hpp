@@ -20,6 +20,12 @@ struct BuildInputs {            // faces in .obj order, device pointers
 // fills nodes[Nr] (compact level order), tris[t], shade[t] (leaf order) and d_order[t] (leaf -> .obj face)
 hipError_t device_build_reference(const BuildInputs& in, const mcpt_bvh_info& bi, DNode* nodes, DTri* tris, DTriShade* shade,
                                   int32_t* d_order, hipStream_t st);
+// The fast hierarchy on the device (MCPT_BUILD_DEVICE_FAST): the triangle records sorted by a 63-bit Morton code on the scene's
+// bounds [lo, hi], a complete 4-ary tree over groups of four consecutive ones, written as the compressed nodes the walk kernels
+// read.  Only ever used to cull (trace_fast.hpp), so its shape cannot change a result.  *cw and *fast_tris are hipMalloc'ed
+// here; levels = inner levels (the walk needs 3 * levels stack entries); absmax = largest |coordinate| of the scene.
+hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], const double hi[3], CwNode** cw, DTri** fast_tris, int* n_nodes,
+                             int* levels, double* absmax, hipStream_t st);
 hipError_t device_gather_tris(const DTri* tris, const int32_t* d_slots, int n, DTri* out, hipStream_t st);
 
 }  // namespace mcpt

@@ -416,7 +416,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
 {
     if (!h || !out) return fail(MCPT_ERR_ARG, "null argument");
     *out = nullptr;
-    if (build_mode != MCPT_BUILD_HOST && build_mode != MCPT_BUILD_DEVICE) return fail(MCPT_ERR_ARG, "bad build mode");
+    if (build_mode != MCPT_BUILD_HOST && build_mode != MCPT_BUILD_DEVICE && build_mode != MCPT_BUILD_DEVICE_FAST) return fail(MCPT_ERR_ARG, "bad build mode");
     const Scene& s = h->s;
     if (build_mode == MCPT_BUILD_HOST && !s.accel_built) return fail(MCPT_ERR_ARG, "scene has no host build; use MCPT_BUILD_DEVICE");
     int ndev = mcpt_device_count();
@@ -433,6 +433,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     d->bi = bi;
     int rc;
     std::vector<int32_t> order;                     // leaf -> .obj face
+    const bool fast_on_device = build_mode == MCPT_BUILD_DEVICE_FAST;
     if (build_mode == MCPT_BUILD_HOST) {
         std::vector<DNode> nodes(bi.Nr);
         for (int i = 0; i < bi.Nr; i++) {
@@ -532,9 +533,10 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         (rc = upload(lcdf, &d->light_cdf)) || (rc = upload(texels, &d->texels)))
         return rc;
 
-    // result-identical fast structure (accel_build.cpp): built on the host from the leaf order, permuted triangle copy gathered on the GPU
+    // result-identical fast structure: SAH hierarchy built on the host from the leaf order (accel_build.cpp), permuted triangle
+    // copy gathered on the GPU -- or, MCPT_BUILD_DEVICE_FAST, a 4-wide tree over the Morton order built on the GPU in place
     FastBvh fb;
-    build_fast_bvh(s.faces, order.data(), t, fb);
+    if (!fast_on_device) build_fast_bvh(s.faces, order.data(), t, fb);
     bool coords_ok = true;                       // every coordinate zero or within [1e-150, 1e150]
     for (const FaceRec& f : s.faces)
         for (int c = 0; c < 3; c++)
@@ -542,7 +544,21 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
                 const double a = std::fabs(v);
                 if (!(a == 0.0 || (a >= 1e-150 && a <= 1e150))) coords_ok = false;
             }
-    {
+    if (fast_on_device) {
+        int n_cw = 0, levels = 0;
+        double amax = 0;
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        for (const FaceRec& f : s.faces)
+            for (int c = 0; c < 3; c++) {
+                const double q[3] = {f.v[c].x, f.v[c].y, f.v[c].z};
+                for (int a = 0; a < 3; a++) { if (q[a] < blo[a]) blo[a] = q[a]; if (q[a] > bhi[a]) bhi[a] = q[a]; }
+            }
+        const hipError_t e = device_build_fast(d->tris, t, blo, bhi, &d->cw_nodes, &d->fast_tris, &n_cw, &levels, &amax, d->stream);
+        if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("device build of the fast hierarchy: ") + hipGetErrorString(e));
+        fb.scene_absmax = amax;
+        fb.max_depth = levels;
+        fb.cw_stack_need = 3 * levels;           // three siblings pushed per inner level on the way down
+    } else {
         int32_t* d_slots = nullptr;
         if ((rc = upload(fb.cw, &d->cw_nodes)) || (rc = upload(fb.leaf_tris, &d_slots))) { (void)hipFree(d_slots); return rc; }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&d->fast_tris), std::max<size_t>(fb.leaf_tris.size(), 1) * sizeof(DTri));

@@ -20,7 +20,8 @@
 namespace mcpt {
 
 #ifndef MCPT_FAST_STACK
-#define MCPT_FAST_STACK 32     /* per-lane traversal stack entries in LDS; accel_build.hpp bounds the hierarchy to it */
+#define MCPT_FAST_STACK 36     /* per-lane traversal stack entries in LDS (36 KB per block); accel_build.hpp bounds the
+                                  hierarchy to it: 35 = 3 x 11 levels of the device-built 4-wide tree (16.7 M triangles) + slack */
 #endif
 #define MCPT_FAST_EMPTY (-2147483647 - 1)
 
