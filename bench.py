@@ -229,7 +229,7 @@ def main():
         steps = max(1, args.steps)
         sec_per_frame = elapsed / steps
         value = rays / elapsed / 1e6
-        # dominant kernel = k_shade_samples (one launch per pixel chunk); algorithmic bytes of its launches
+        # dominant kernel = k_wf_trace (one launch per bounce iteration); algorithmic bytes of its launches
         prim = tot["rays_primary"]
         # numerator: only what k_wf_trace itself did (its own device counters); the samples term is the radiance the frame writes
         # and folds, carried here because the contract's per-unit figure includes it
