@@ -14,11 +14,15 @@
 // depth-bounded so the traversal stack fits the LDS budget, children's boxes stored in the parent so one record
 // fetch tests both children.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #include "accel_build.hpp"
 
@@ -41,20 +45,18 @@ struct Box {
     }
 };
 
+// A subtree the top-level pass leaves to a worker thread: primitives idx[b, e) at `depth`, to be hung under parent.child[slot].
+struct Subtree { int b, e, depth; int32_t parent; int slot; };
+
 struct Builder {
     const std::vector<Box>& prim;       // exact leaf boxes, indexed by leaf (Morton) order k
-    std::vector<Vec3> cen;
-    std::vector<int32_t> idx;           // permutation being partitioned
+    const std::vector<Vec3>& cen;       // their centres
+    std::vector<int32_t>& idx;          // permutation being partitioned (workers own disjoint ranges of it)
     FastBvh& out;
+    std::vector<Subtree>* defer = nullptr;   // top-level pass only: subtrees of at most `cut` primitives are recorded, not built
+    int cut = 0;
 
-    Builder(const std::vector<Box>& p, FastBvh& o) : prim(p), out(o)
-    {
-        cen.resize(p.size());
-        for (size_t i = 0; i < p.size(); i++)
-            cen[i] = Vec3{0.5 * (p[i].lo[0] + p[i].hi[0]), 0.5 * (p[i].lo[1] + p[i].hi[1]), 0.5 * (p[i].lo[2] + p[i].hi[2])};
-        idx.resize(p.size());
-        std::iota(idx.begin(), idx.end(), 0);
-    }
+    Builder(const std::vector<Box>& p, const std::vector<Vec3>& c, std::vector<int32_t>& i, FastBvh& o) : prim(p), cen(c), idx(i), out(o) {}
 
     static int ceil_log2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
 
@@ -72,6 +74,12 @@ struct Builder {
         std::sort(idx.begin() + b, idx.begin() + e);
         for (int i = b; i < e; i++) out.leaf_tris.push_back(idx[i]);
         return -1 - ((start << 4) | (e - b - 1));
+    }
+
+    int32_t child(int b, int e, int depth, int32_t parent, int slot)
+    {
+        if (defer && e - b <= cut && e - b > 1) { defer->push_back(Subtree{b, e, depth, parent, slot}); return kFastEmpty; }
+        return build(b, e, depth);
     }
 
     // returns child reference (>=0 inner node index, <0 leaf) for prims [b,e)
@@ -150,8 +158,8 @@ struct Builder {
         const int32_t self = int32_t(out.nodes.size());
         out.nodes.emplace_back();
         const Box lb = bounds(b, mid), rb = bounds(mid, e);
-        const int32_t l = build(b, mid, depth + 1);
-        const int32_t r = build(mid, e, depth + 1);
+        const int32_t l = child(b, mid, depth + 1, self, 0);
+        const int32_t r = child(mid, e, depth + 1, self, 1);
         FastNode& nd = out.nodes[self];
         for (int a = 0; a < 3; a++) { nd.lo[0][a] = lb.lo[a]; nd.hi[0][a] = lb.hi[a]; nd.lo[1][a] = rb.lo[a]; nd.hi[1][a] = rb.hi[a]; }
         nd.child[0] = l; nd.child[1] = r;
@@ -164,19 +172,26 @@ struct Builder {
 namespace {
 
 // ---- collapse the binary tree into compressed 4-wide nodes -----------------------------------------------------------
+// A binary subtree the top-level collapse leaves to a worker thread
+struct CollapseTask { int node, budget; int32_t parent; int slot; };
+
 struct Collapser {
     const FastBvh& in;
     std::vector<CwNode>& out;
-    std::vector<int> height;            // binary height below each FastNode
+    std::vector<int>& height;           // binary height below each FastNode
+    std::vector<int>& count;            // FastNodes in the subtree of each FastNode
+    std::vector<CollapseTask>* defer = nullptr;   // top-level pass only: subtrees of at most `cut` binary nodes are recorded
+    int cut = 0;
 
     int compute_height(int n)
     {
-        int h = 0;
+        int h = 0, cnt = 1;
         for (int c = 0; c < 2; c++) {
             const int32_t r = in.nodes[n].child[c];
-            if (r >= 0) h = std::max(h, 1 + compute_height(r));
+            if (r >= 0) { h = std::max(h, 1 + compute_height(r)); cnt += count[r]; }
             else h = std::max(h, 1);
         }
+        count[n] = cnt;
         return height[n] = h;
     }
 
@@ -224,8 +239,10 @@ struct Collapser {
         int below = 0;
         int32_t refs[4] = {kFastEmpty, kFastEmpty, kFastEmpty, kFastEmpty};
         for (size_t i = 0; i < kids.size(); i++) {
-            if (kids[i].ref >= 0) { int nd = 0; refs[i] = emit(kids[i].ref, budget - pushes, nd); below = std::max(below, nd); }
-            else refs[i] = kids[i].ref;
+            if (kids[i].ref >= 0) {
+                if (defer && count[kids[i].ref] <= cut) { defer->push_back(CollapseTask{kids[i].ref, budget - pushes, self, int(i)}); continue; }
+                int nd = 0; refs[i] = emit(kids[i].ref, budget - pushes, nd); below = std::max(below, nd);
+            } else refs[i] = kids[i].ref;
         }
         need = pushes + below;
         // quantise
@@ -285,10 +302,57 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
         }
     }
     out.scene_absmax = amax;
-    Builder bld(prim, out);
+    const bool talk = std::getenv("MCPT_PRINT_DIAG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<Vec3> cen(static_cast<size_t>(t), Vec3{});
+    for (int i = 0; i < t; i++)
+        cen[size_t(i)] = Vec3{0.5 * (prim[size_t(i)].lo[0] + prim[size_t(i)].hi[0]), 0.5 * (prim[size_t(i)].lo[1] + prim[size_t(i)].hi[1]),
+                              0.5 * (prim[size_t(i)].lo[2] + prim[size_t(i)].hi[2])};
+    std::vector<int32_t> idx(static_cast<size_t>(t), 0);
+    std::iota(idx.begin(), idx.end(), 0);
+    Builder bld(prim, cen, idx, out);
     out.nodes.reserve(size_t(t));
     out.leaf_tris.reserve(size_t(t));
+    // Large scenes: the top of the tree is split here, subtrees of <= t/64 primitives are built by worker threads (each into
+    // its own arrays, over its own range of idx) and appended in a fixed order, so the result does not depend on timing.
+    std::vector<Subtree> subtrees;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int workers = int(std::min(16u, hw));
+    if (t >= (1 << 17) && workers > 1 && !std::getenv("MCPT_BUILD_SERIAL")) { bld.defer = &subtrees; bld.cut = std::max(4096, t / 64); }
     const int32_t root = bld.build(0, t, 0);
+    const auto t_top = std::chrono::steady_clock::now();
+    if (talk) std::fprintf(stderr, "fast hierarchy (host): top of the tree %.2f s, %zu subtrees for %d threads\n",
+                           std::chrono::duration<double>(t_top - t0).count(), subtrees.size(), workers);
+    if (!subtrees.empty()) {
+        std::vector<FastBvh> part(subtrees.size());
+        std::vector<int32_t> part_root(subtrees.size(), kFastEmpty);
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < subtrees.size(); i = next.fetch_add(1)) {
+                Builder wb(prim, cen, idx, part[i]);
+                part_root[i] = wb.build(subtrees[i].b, subtrees[i].e, subtrees[i].depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < workers; w++) pool.emplace_back(work);
+        work();
+        for (std::thread& th : pool) th.join();
+        if (talk) std::fprintf(stderr, "fast hierarchy (host): subtrees built %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_top).count());
+        for (size_t i = 0; i < subtrees.size(); i++) {
+            const int32_t node_off = int32_t(out.nodes.size()), leaf_off = int32_t(out.leaf_tris.size());
+            auto moved = [&](int32_t r) -> int32_t {
+                if (r == kFastEmpty) return r;
+                if (r >= 0) return r + node_off;
+                const int32_t v = -1 - r;
+                return -1 - ((((v >> 4) + leaf_off) << 4) | (v & 15));
+            };
+            for (FastNode nd : part[i].nodes) { nd.child[0] = moved(nd.child[0]); nd.child[1] = moved(nd.child[1]); out.nodes.push_back(nd); }
+            out.leaf_tris.insert(out.leaf_tris.end(), part[i].leaf_tris.begin(), part[i].leaf_tris.end());
+            out.nodes[size_t(subtrees[i].parent)].child[subtrees[i].slot] = moved(part_root[i]);
+            out.max_depth = std::max(out.max_depth, part[i].max_depth);
+            part[i] = FastBvh();
+        }
+    }
     if (root < 0) {
         // a single leaf: wrap it in a root whose second child is an empty leaf with an inverted box
         FastNode nd{};
@@ -300,12 +364,49 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
         nd.child[0] = root; nd.child[1] = kFastEmpty;
         out.nodes.push_back(nd);
     }
-    Collapser col{out, out.cw, std::vector<int>(out.nodes.size(), 0)};
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<int> height(out.nodes.size(), 0), count(out.nodes.size(), 0);
+    Collapser col{out, out.cw, height, count};
     col.compute_height(0);
     out.cw.reserve(out.nodes.size());
+    std::vector<CollapseTask> ctasks;
+    if (!subtrees.empty()) { col.defer = &ctasks; col.cut = std::max<int>(4096, int(out.nodes.size() / 64)); }
     int need = 0;
     col.emit(0, kFastMaxDepth - 1, need);
+    if (!ctasks.empty()) {
+        // same scheme as the SAH pass: workers collapse whole subtrees into their own arrays, appended in task order
+        std::vector<std::vector<CwNode>> part(ctasks.size());
+        std::vector<int> part_need(ctasks.size(), 0);
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < ctasks.size(); i = next.fetch_add(1)) {
+                Collapser wc{out, part[i], height, count};
+                part[i].reserve(size_t(count[ctasks[i].node]));
+                wc.emit(ctasks[i].node, ctasks[i].budget, part_need[i]);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < workers; w++) pool.emplace_back(work);
+        work();
+        for (std::thread& th : pool) th.join();
+        for (size_t i = 0; i < ctasks.size(); i++) {
+            const int32_t off = int32_t(out.cw.size());
+            for (CwNode nd : part[i]) {
+                for (int c = 0; c < 4; c++) if (nd.child[c] >= 0) nd.child[c] += off;
+                out.cw.push_back(nd);
+            }
+            out.cw[size_t(ctasks[i].parent)].child[ctasks[i].slot] = off;            // a worker's root is its node 0
+            need = std::max(need, (kFastMaxDepth - 1 - ctasks[i].budget) + part_need[i]);   // pushes above the subtree + below
+            std::vector<CwNode>().swap(part[i]);
+        }
+    }
     out.cw_stack_need = need;
+    if (talk) {
+        const auto t2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "fast hierarchy (host): %d triangles, SAH build %.2f s, collapse %.2f s, %zu binary / %zu wide nodes, depth %d, stack need %d\n", t,
+                     std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(), out.nodes.size(), out.cw.size(),
+                     out.max_depth, need);
+    }
 }
 
 }  // namespace mcpt

@@ -240,7 +240,7 @@ def test_device_build_equals_host_build(mcpt, name, tmp_path):
     host build (bvh_build.cpp): every node box, the leaf order, and the rendered image, bit for bit."""
     from montecarlopathtracing_amd import synthetic
     if name == "synthetic":
-        g = synthetic.generate(60000, width=96, height=54)
+        g = synthetic.generate(150000, width=96, height=54)     # above 2^17 triangles: the host's SAH build runs its worker threads
         args = (g["v"], g["vn"], g["material"], g["material_rec"], g["light_material"], g["light_radiance"], g["eye"], g["look_at"],
                 g["up"], g["fovy"], g["width"], g["height"])
         sc = mcpt.Scene.from_arrays(*args)
