@@ -2,7 +2,10 @@
 // its 64 lanes busy although rays take very different numbers of steps.
 //
 //   * Every wave owns a private range of ray slots (a chunk claimed with ONE atomic on the queue head; a single word
-//     saturates near 88 dequeues/us on this chip, so claims are per chunk, never per ray).  Lanes that finish a ray
+//     saturates near 88 dequeues/us on this chip, so claims are per chunk, never per ray).  The head counts tickets, not
+//     slots: the first seven eighths of the slots go out in large chunks, the rest in chunks of MCPT_TAIL_CHUNK, so that
+//     the waves run dry within one small chunk of each other (with 2048-slot chunks to the end, the last waves of a
+//     6-ms launch worked alone for most of a millisecond: 2.5 % of the frame).  Lanes that finish a ray
 //     take the next slots of the range: the refill is a ballot + prefix count, no memory traffic.
 //   * Each lane is a small state machine: IDLE, INNER (about to test the two children of an inner node),
 //     TRI (walking the triangles of a leaf).  Per wave iteration the wave executes ONE phase -- the one most lanes are
@@ -21,6 +24,9 @@ namespace mcpt {
 
 #ifndef MCPT_REFILL_LANES
 #define MCPT_REFILL_LANES 24        /* refill as soon as this many lanes are idle (sweep: 8: +6 %, 16: +1 %, 32: +1 %) */
+#endif
+#ifndef MCPT_TAIL_CHUNK
+#define MCPT_TAIL_CHUNK 256         /* slots per claim in the last eighth of a launch */
 #endif
 #ifndef MCPT_INNER_BURST
 #define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
@@ -46,6 +52,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     const CwNode* __restrict__ nodes = F.cw;
     const DTri* __restrict__ tris = F.tris;
     const long long total = src.total();
+    // ticket k < big_tickets: slots [k * chunk, (k + 1) * chunk); later tickets: MCPT_TAIL_CHUNK slots each
+    const long long small = chunk < MCPT_TAIL_CHUNK ? chunk : MCPT_TAIL_CHUNK;
+    const long long big_tickets = (total - total / 8) / chunk;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int* __restrict__ rayflag = reinterpret_cast<int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
@@ -77,10 +86,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         if (queue_empty) return;
         if (next >= range_end) {
             unsigned long long got = 0;
-            if (lane == 0) got = atomicAdd(&queue->head, (unsigned long long)chunk);
+            if (lane == 0) got = atomicAdd(&queue->head, 1ull);
             got = __shfl(got, 0, 64);
-            next = (long long)got;
-            range_end = next + chunk < total ? next + chunk : total;
+            const long long ticket = (long long)got;
+            const long long size = ticket < big_tickets ? chunk : small;
+            next = ticket < big_tickets ? ticket * chunk : big_tickets * chunk + (ticket - big_tickets) * small;
+            range_end = next + size < total ? next + size : total;
             if (next >= total) { queue_empty = true; return; }
         }
         const long long avail = range_end - next;

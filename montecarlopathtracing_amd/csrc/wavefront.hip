@@ -245,22 +245,22 @@ struct WfRaySource {
 };
 
 // persistent fast walk
-__device__ __forceinline__ long long wf_chunk(long long total, int min_chunk)
+__device__ __forceinline__ long long wf_chunk(long long total, int min_chunk, int max_chunk)
 {
     const long long waves = (long long)gridDim.x * 4;
     long long c = total / (waves * 4);
     c = (c / 64) * 64;
-    return c < min_chunk ? min_chunk : (c > 2048 ? 2048 : c);
+    return c < min_chunk ? min_chunk : (c > max_chunk ? max_chunk : c);
 }
 
 #ifndef MCPT_TRACE_WAVES
 #define MCPT_TRACE_WAVES 3   /* waves per SIMD: 168 VGPRs, 45 KB of LDS per block */
 #endif
-__global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, int min_chunk)
+__global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, int min_chunk, int max_chunk)
 {
     const long long n_paths = a.counts->n_next;
     if (n_paths <= (long long)a.finish_below) return;                  // nothing left, or k_wf_finish has taken the paths
-    const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk);
+    const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk, max_chunk);
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
     WfRaySource src; src.a = a; src.n_paths = n_paths;
@@ -532,7 +532,8 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
     // every claim is an atomic on one word (~88 per microsecond on this chip): below this many rays per claim the queue head,
     // not the walk, bounds a launch of a million rays
     static const int min_chunk = [] { const char* e = std::getenv("MCPT_TRACE_MIN_CHUNK"); const int v = e ? std::atoi(e) : 0; return v >= 64 ? v / 64 * 64 : 256; }();
-    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, min_chunk);
+    static const int max_chunk = [] { const char* e = std::getenv("MCPT_TRACE_MAX_CHUNK"); const int v = e ? std::atoi(e) : 0; return v >= 64 ? v / 64 * 64 : 2048; }();
+    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, min_chunk, max_chunk < min_chunk ? min_chunk : max_chunk);
     hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 64 ? g : 64), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
 }
 

@@ -41,7 +41,7 @@ struct WfRays {
 };
 
 struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
-    unsigned long long head;        // next unclaimed ray slot
+    unsigned long long head;        // next ticket (trace_persistent.hpp maps tickets to ray slots)
     unsigned int slow_count;        // rays deferred to the reference-shaped walk (may exceed the list capacity)
     unsigned int pad[13];
 };
