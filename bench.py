@@ -128,7 +128,8 @@ def main():
     ap.add_argument("--tris", type=int, default=10_000_000, help="--scene synthetic: number of lattice triangles")
     ap.add_argument("--build", default="default", choices=["default", "host", "device", "device_fast"],
                     help="where the BVHs are built (mcpt_device_create_ex); device_fast: the fast walk's hierarchy on the GPU too")
-    ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: render only rank 0's tiles of an N-rank partition on this GPU")
+    ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: render only one rank's tiles of an N-rank partition on this GPU")
+    ap.add_argument("--sim-rank", type=int, default=0, help="with --sim-world: which rank's tiles")
     args = ap.parse_args()
 
     import torch
@@ -185,7 +186,7 @@ def main():
                 import torch as _t
                 self.frame = _t.zeros((scene.info.height * scene.info.width, 3), dtype=_t.float64, device=tdev)
             def render(self, spp, seed=0, stats=None, flags=0):
-                dev.render_device(self.frame.data_ptr(), spp, seed, 0, args.sim_world, 0, 0, flags, stats,
+                dev.render_device(self.frame.data_ptr(), spp, seed, args.sim_rank, args.sim_world, 0, 0, flags, stats,
                                   torch.cuda.current_stream(tdev).cuda_stream)
                 return self.frame
         rr = _Sim()
