@@ -376,3 +376,58 @@ def test_fast_hierarchy_built_on_device(mcpt, oracle, name):
     assert np.array_equal(_bits(a), _bits(b)) and a.sum() > 0
     host.close()
     dev.close()
+
+
+EDGE_MTL = "newmtl grey\nKd 0.6 0.5 0.4\nKs 0 0 0\nNs 1\nNi 1\nnewmtl lamp\nKd 0 0 0\nKs 0 0 0\nNs 1\nNi 1\n"
+EDGE_OBJ_HEAD = ("v -2 0 -2\nv 2 0 -2\nv 2 0 2\nv -2 0 2\nv -0.5 1.9 -0.5\nv 0.5 1.9 -0.5\nv 0.5 1.9 0.5\nv -0.5 1.9 0.5\n"
+                 "vn 0 1 0\nvn 0 -1 0\nvt 0 0\n")
+EDGE_CASES = {
+    # a single triangle and nothing else: one leaf, a root that is a leaf, every path ends after one vertex, no light at all
+    "one-triangle-no-light": ("usemtl grey\nf 1/1/1 2/1/1 3/1/1\n", ""),
+    # floor + lamp, plus a zero-area triangle (NaN normal: the triangle test can never pass) and a repeated face (exact tie in t)
+    "degenerate-and-duplicate": ("usemtl grey\nf 1/1/1 2/1/1 3/1/1\nf 1/1/1 3/1/1 4/1/1\nf 1/1/1 1/1/1 2/1/1\nf 1/1/1 2/1/1 3/1/1\n"
+                                 "usemtl lamp\nf 5/2/1 6/2/1 7/2/1\nf 5/2/1 7/2/1 8/2/1\n", "mtlname lamp 12 12 12\n"),
+    # the camera names a light twice: light_map keeps the last entry, lights[] both (two shadow rays per vertex, nl = 2)
+    "light-listed-twice": ("usemtl grey\nf 1/1/1 2/1/1 3/1/1\nf 1/1/1 3/1/1 4/1/1\nusemtl lamp\nf 5/2/1 6/2/1 7/2/1\nf 5/2/1 7/2/1 8/2/1\n",
+                           "mtlname lamp 5 5 5\nmtlname lamp 7 7 7\n"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+@pytest.mark.parametrize("size", [(1, 1), (33, 17)])
+def test_edge_scenes(mcpt, oracle, tmp_path, case, size):
+    """Smallest and oddest inputs the reader accepts (see EDGE_CASES), at a 1x1 frame and a ragged one (neither a multiple of
+    the 32x8 tile nor of a wave): closest hit bit-exact in both walks, image against the oracle, every pipeline the same bits."""
+    faces, lights = EDGE_CASES[case]
+    w, h = size
+    d = str(tmp_path) + os.sep
+    open(d + "e.obj", "w").write(EDGE_OBJ_HEAD + faces)
+    open(d + "e.mtl", "w").write(EDGE_MTL)
+    open(d + "e.camera", "w").write("eye 0.3 1.0 3.5\nlookat 0 0.8 0\nup 0 1 0\nfovy 50\nwidth %d\nheight %d\n%s" % (w, h, lights))
+    osc = oracle.OracleScene(d + "e", texture_dir=d)
+    sc = mcpt.Scene(d, "e")
+    dev = mcpt.Device(sc, 0)
+    rays = make_rays(osc, 4000, seed=3)
+    of, ot, op, opn = osc.trace_closest(rays)
+    for mode in (mcpt.TRACE_FAST, mcpt.TRACE_REFERENCE):
+        dev.set_trace_mode(mode)
+        gf, gt, gp, gpn = dev.ray_intersect(rays)
+        assert np.array_equal(of, gf)
+        hh = of >= 0
+        assert np.array_equal(_bits(ot[hh]), _bits(gt[hh])) and np.array_equal(_bits(op[hh]), _bits(gp[hh]))
+    dev.set_trace_mode(mcpt.TRACE_FAST)
+    ref = osc.render(5, seed=2)
+    a = dev.generateImg(5, seed=2)
+    b = dev.generateImg(5, seed=2, flags=mcpt.RENDER_MEGAKERNEL)
+    parts = np.zeros_like(a)
+    for r in range(3):
+        dev.generateImg(5, seed=2, rank=r, world=3, img=parts)
+    assert np.array_equal(_bits(a), _bits(b)) and np.array_equal(_bits(a), _bits(parts))
+    assert np.allclose(a, ref, rtol=1e-6, atol=1e-12)
+    if not lights:
+        assert not a.any()
+    elif w > 1:
+        assert a.sum() > 0
+    dev.close()
+    sc.close()
+    osc.close()
