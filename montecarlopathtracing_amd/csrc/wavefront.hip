@@ -385,9 +385,11 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
             } else vertex_surface(S, leaf, p, m, pn, kd);
         }
 
-        // ---- direct light: one shadow ray per light, traced by all lanes together
+        // ---- the rays of this step: one shadow ray per light and the bounce ray (Russian roulette + nextRay, or the stored ones)
         V3 L_dir = mk(0, 0, 0);
-        int sample_mat = -1;
+        int sample_mat = -1, expect0 = -2;
+        V3 c0 = mk(0, 0, 0);
+        Ray rs; rs.o = p; rs.d = mk(1, 1, 1);
         for (int l = 0; l < nl; l++) {
             int expect = -2;
             V3 c = mk(0, 0, 0);
@@ -399,8 +401,9 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
                 expect = a.out.expect[(long long)l * cap + j];
                 if (expect != -2) { c = ldc(a.out.c + (long long)l * 3 * cap, cap, j); r.d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j); }
             }
+            if (expect != -2) r.o = p + r.d * 0.01;
+            if (nl == 1) { expect0 = expect; c0 = c; rs = r; break; }       // traced below, together with the bounce ray
             if (expect != -2) {
-                r.o = p + r.d * 0.01;
                 Hit h;
                 const bool ok = trace_lane_fast(S, r, h, w, stack, 256);
                 const bool vis = (ok ? S.tris[h.leaf].material : -1) == expect;
@@ -409,10 +412,6 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
                 L_dir.z += vis ? c.z : c.z * 0.0;
             }
         }
-        if (mode == M_ADOPTED && folded) L = L + L_dir;                 // its c was stored as T * c
-        else L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
-
-        // ---- bounce: Russian roulette + nextRay (or the stored ray), closest hit, next vertex
         int bt = -1;
         V3 wgt = mk(1, 1, 1);
         Ray br; br.o = p; br.d = mk(1, 1, 1);
@@ -423,16 +422,50 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
             bt = a.out.btype[j];
             if (bt >= 0) { br.d = ldc(a.out.bdir, cap, j); if (!folded) wgt = ldc(a.out.w, cap, j); }
         }
-        bool goes_on = false;
-        if (bt >= 0) {
-            if (!(bt & MCPT_BT_NO_OFFSET)) br.o = p + br.d * 0.01;
-            Hit h;
-            if (trace_lane_fast(S, br, h, w, stack, 256)) {
-                // an adopted path with one light already holds the throughput after its bounce
-                if (!(mode == M_ADOPTED && folded)) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
-                leaf = h.leaf; p = h.p; dir = neg(br.d); in_type = bt & 7; depth++;
-                goes_on = true;
+        if (bt >= 0 && !(bt & MCPT_BT_NO_OFFSET)) br.o = p + br.d * 0.01;
+
+        // ---- closest hits.  One light: a lane with both rays hands its shadow ray to lane ^ 32 when that lane has no path, so
+        // the two walks of a vertex run side by side -- it is the last few long paths, alone in their waves, that decide how long
+        // this kernel runs.  Lanes without a free partner walk the shadow ray first and the bounce ray in a second round.
+        bool b_ok = false;
+        Hit b_hit; b_hit.leaf = -1; b_hit.t = 0; b_hit.p = mk(0, 0, 0);
+        if (nl == 1) {
+            const bool have_s = expect0 != -2, have_b = bt >= 0;
+            const int partner = lane ^ 32;
+            const unsigned long long idle_now = __ballot(mode == M_IDLE);
+            const bool give = have_s && have_b && ((idle_now >> partner) & 1ull);
+            Ray rin;
+            rin.o = mk(__shfl(rs.o.x, partner, 64), __shfl(rs.o.y, partner, 64), __shfl(rs.o.z, partner, 64));
+            rin.d = mk(__shfl(rs.d.x, partner, 64), __shfl(rs.d.y, partner, 64), __shfl(rs.d.z, partner, 64));
+            const int partner_gives = __shfl((int)give, partner, 64);      // every lane takes part: not under a short-circuit
+            const bool helping = mode == M_IDLE && partner_gives != 0;
+            // first round: the helper's ray, or the bounce ray if the shadow ray was handed over, or the own shadow ray
+            const int kind = helping ? 2 : (give ? 1 : (have_s ? 0 : (have_b ? 1 : -1)));
+            Ray r1 = helping ? rin : (kind == 1 ? br : rs);
+            Hit h1; h1.leaf = -1; h1.t = 0; h1.p = mk(0, 0, 0);
+            bool ok1 = false;
+            if (kind >= 0) ok1 = trace_lane_fast(S, r1, h1, w, stack, 256);
+            const int mat1 = (kind == 0 || kind == 2) ? (ok1 ? S.tris[h1.leaf].material : -1) : -1;
+            const int mat_helped = __shfl(mat1, partner, 64);
+            if (have_s) {
+                const bool vis = (give ? mat_helped : mat1) == expect0;
+                L_dir.x += vis ? c0.x : c0.x * 0.0;
+                L_dir.y += vis ? c0.y : c0.y * 0.0;
+                L_dir.z += vis ? c0.z : c0.z * 0.0;
             }
+            if (kind == 1) { b_ok = ok1; b_hit = h1; }
+            const bool second = have_b && kind == 0;
+            if (__ballot(second)) { if (second) b_ok = trace_lane_fast(S, br, b_hit, w, stack, 256); }
+        } else if (bt >= 0) b_ok = trace_lane_fast(S, br, b_hit, w, stack, 256);
+        if (mode == M_ADOPTED && folded) L = L + L_dir;                 // its c was stored as T * c
+        else L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
+
+        bool goes_on = false;
+        if (bt >= 0 && b_ok) {
+            // an adopted path with one light already holds the throughput after its bounce
+            if (!(mode == M_ADOPTED && folded)) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
+            leaf = b_hit.leaf; p = b_hit.p; dir = neg(br.d); in_type = bt & 7; depth++;
+            goes_on = true;
         }
         if (mode != M_IDLE) {
             if (goes_on) mode = M_VERTEX;
