@@ -55,6 +55,8 @@ struct Builder {
     FastBvh& out;
     std::vector<Subtree>* defer = nullptr;   // top-level pass only: subtrees of at most `cut` primitives are recorded, not built
     int cut = 0;
+    int max_leaf = kFastDefaultLeaf;         // most primitives a leaf may hold
+    int depth_limit = kFastMaxDepth;         // binary depth the tree must stay below (the walk's stack)
 
     Builder(const std::vector<Box>& p, const std::vector<Vec3>& c, std::vector<int32_t>& i, FastBvh& o) : prim(p), cen(c), idx(i), out(o) {}
 
@@ -88,7 +90,7 @@ struct Builder {
         const int n = e - b;
         out.max_depth = std::max(out.max_depth, depth);
         if (n <= 1) return make_leaf(b, e);
-        const bool force_balanced = depth + ceil_log2(n) >= kFastMaxDepth - 1;
+        const bool force_balanced = depth + ceil_log2(n) >= depth_limit - 1;
         Box cb; cb.reset();
         for (int i = b; i < e; i++) {
             const Vec3& c = cen[idx[i]];
@@ -127,7 +129,7 @@ struct Builder {
             }
             if (best_axis >= 0) {
                 const double split_cost = kCostNode + kCostTri * best / std::max(parent_area, 1e-300);
-                if (n <= kMaxLeafRt && kCostTri * n <= split_cost) return make_leaf(b, e);
+                if (n <= max_leaf && kCostTri * n <= split_cost) return make_leaf(b, e);
                 const int a = best_axis;
                 const double ext = cb.hi[a] - cb.lo[a];
                 const double scale = kBins * (1.0 - 1e-12) / ext;
@@ -140,7 +142,7 @@ struct Builder {
                 });
                 mid = int(it - idx.begin());
                 if (mid == b || mid == e) mid = -1;
-            } else if (n <= kMaxLeafRt) {
+            } else if (n <= max_leaf) {
                 return make_leaf(b, e);     // all centroids coincide
             }
         }
@@ -282,6 +284,8 @@ struct Collapser {
 
 }  // namespace
 
+static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int budget0, FastBvh& out);
+
 void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out)
 {
     out = FastBvh();
@@ -302,6 +306,29 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
         }
     }
     out.scene_absmax = amax;
+    build_from_boxes(prim, kMaxLeafRt, kFastMaxDepth - 1, out);
+}
+
+// Upper part of a two-part hierarchy (MCPT_BUILD_DEVICE_FAST): the SAH tree over the boxes of clusters the GPU has built, one
+// cluster per leaf.  lower_need = traversal stack entries a cluster's own subtree needs.  A leaf child of out.cw comes back as
+// -1 - cluster; the caller turns it into the index of that cluster's root node.
+void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out)
+{
+    out = FastBvh();
+    std::vector<Box> prim(static_cast<size_t>(n), Box{});
+    for (int i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) { prim[size_t(i)].lo[a] = boxes6[size_t(i) * 6 + a]; prim[size_t(i)].hi[a] = boxes6[size_t(i) * 6 + 3 + a]; }
+    build_from_boxes(prim, 1, kFastMaxDepth - 1 - lower_need, out);
+    for (CwNode& nd : out.cw)
+        for (int c = 0; c < 4; c++)
+            if (nd.child[c] < 0 && nd.child[c] != kFastEmpty) nd.child[c] = -1 - out.leaf_tris[size_t((-1 - nd.child[c]) >> 4)];
+    out.cw_stack_need += lower_need;
+}
+
+// binned-SAH binary tree over the boxes, collapsed to compressed 4-wide nodes whose walk needs at most budget0 stack entries
+static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int budget0, FastBvh& out)
+{
+    const int t = int(prim.size());
     const bool talk = std::getenv("MCPT_PRINT_DIAG") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<Vec3> cen(static_cast<size_t>(t), Vec3{});
@@ -311,6 +338,7 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
     std::vector<int32_t> idx(static_cast<size_t>(t), 0);
     std::iota(idx.begin(), idx.end(), 0);
     Builder bld(prim, cen, idx, out);
+    bld.max_leaf = max_leaf; bld.depth_limit = budget0 + 1;
     out.nodes.reserve(size_t(t));
     out.leaf_tris.reserve(size_t(t));
     // Large scenes: the top of the tree is split here, subtrees of <= t/64 primitives are built by worker threads (each into
@@ -330,6 +358,7 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
         auto work = [&]() {
             for (size_t i = next.fetch_add(1); i < subtrees.size(); i = next.fetch_add(1)) {
                 Builder wb(prim, cen, idx, part[i]);
+                wb.max_leaf = max_leaf; wb.depth_limit = budget0 + 1;
                 part_root[i] = wb.build(subtrees[i].b, subtrees[i].e, subtrees[i].depth);
             }
         };
@@ -372,7 +401,7 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
     std::vector<CollapseTask> ctasks;
     if (!subtrees.empty()) { col.defer = &ctasks; col.cut = std::max<int>(4096, int(out.nodes.size() / 64)); }
     int need = 0;
-    col.emit(0, kFastMaxDepth - 1, need);
+    col.emit(0, budget0, need);
     if (!ctasks.empty()) {
         // same scheme as the SAH pass: workers collapse whole subtrees into their own arrays, appended in task order
         std::vector<std::vector<CwNode>> part(ctasks.size());
@@ -396,7 +425,7 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
                 out.cw.push_back(nd);
             }
             out.cw[size_t(ctasks[i].parent)].child[ctasks[i].slot] = off;            // a worker's root is its node 0
-            need = std::max(need, (kFastMaxDepth - 1 - ctasks[i].budget) + part_need[i]);   // pushes above the subtree + below
+            need = std::max(need, (budget0 - ctasks[i].budget) + part_need[i]);   // pushes above the subtree + below
             std::vector<CwNode>().swap(part[i]);
         }
     }

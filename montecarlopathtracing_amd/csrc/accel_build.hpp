@@ -27,5 +27,7 @@ struct FastBvh {
 
 // order[k] = .obj face held by reference leaf k
 void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out);
+// upper part over n GPU-built clusters given by their boxes (lo[3], hi[3]); see accel_build.cpp
+void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out);
 
 }  // namespace mcpt

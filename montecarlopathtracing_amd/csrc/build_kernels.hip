@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <vector>
 #include <hipcub/hipcub.hpp>
 
 #include "build_kernels.hpp"
@@ -133,14 +134,14 @@ __global__ void k_fast_keys(const DTri* __restrict__ tris, int t, FastDomain dom
 }
 
 // box of fast leaf g = triangles 4g .. 4g+3 of the sorted copy (each triangle's own box is the reference's, BVH.cpp:87-97)
-__global__ void k_fast_leaf_boxes(const DTri* __restrict__ tris, int t, int groups, FBox* __restrict__ boxes, unsigned long long* __restrict__ absmax_bits)
+__global__ void k_fast_leaf_boxes(const DTri* __restrict__ tris, int t, int per_leaf, int groups, FBox* __restrict__ boxes, unsigned long long* __restrict__ absmax_bits)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     double am = 0.0;
     if (g < groups) {
         FBox b;
         for (int a = 0; a < 3; a++) { b.lo[a] = __builtin_inf(); b.hi[a] = -__builtin_inf(); }
-        const int first = 4 * g, end = first + 4 < t ? first + 4 : t;
+        const int first = per_leaf * g, end = first + per_leaf < t ? first + per_leaf : t;
         for (int k = first; k < end; k++) {
             const DTri* tr = tris + k;
             for (int a = 0; a < 3; a++) {
@@ -160,7 +161,7 @@ __global__ void k_fast_leaf_boxes(const DTri* __restrict__ tris, int t, int grou
 // One level: node i takes children 4i .. 4i+3 of the level below (nodes, or fast leaves when leaf_level), stores its own exact
 // box for the level above and its compressed record: per axis a grid origin p (fp32, rounded down), a power-of-two step and the
 // children's planes as 8-bit offsets rounded outward, verified in fp64 (the same rule as the host builder, accel_build.cpp).
-__global__ void k_fast_level(const FBox* __restrict__ child_boxes, int n_children, int child_base, int leaf_level, int t,
+__global__ void k_fast_level(const FBox* __restrict__ child_boxes, int n_children, int child_base, int per_leaf /* 0: children are nodes */, int t,
                              FBox* __restrict__ my_boxes, CwNode* __restrict__ nodes, int node_base, int n_nodes)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,16 +204,29 @@ __global__ void k_fast_level(const FBox* __restrict__ child_boxes, int n_childre
     for (int c = 0; c < 4; c++) {
         const int ci = 4 * i + c;
         if (ci >= n_children) nd.child[c] = (int32_t)0x80000000;               // MCPT_FAST_EMPTY
-        else if (leaf_level) { const int first = 4 * ci, count = (first + 4 < t ? 4 : t - first); nd.child[c] = -1 - ((first << 4) | (count - 1)); }
+        else if (per_leaf) { const int first = per_leaf * ci, count = (first + per_leaf < t ? per_leaf : t - first); nd.child[c] = -1 - ((first << 4) | (count - 1)); }
         else nd.child[c] = child_base + ci;
     }
     nodes[node_base + i] = nd;
 }
 
-hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], const double hi[3], CwNode** cw, DTri** fast_tris, int* n_nodes, int* levels,
-                             double* absmax, hipStream_t st)
+__global__ void k_offset_children(CwNode* __restrict__ nodes, int n, int off)
 {
-    *cw = nullptr; *fast_tris = nullptr; *n_nodes = 0; *levels = 0; *absmax = 0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < 4; c++) { const int32_t r = nodes[i].child[c]; if (r >= 0) nodes[i].child[c] = r + off; }
+}
+
+hipError_t device_offset_children(CwNode* nodes, int n, int off, hipStream_t st)
+{
+    if (n > 0 && off != 0) hipLaunchKernelGGL(k_offset_children, dim3((n + 255) / 256), dim3(256), 0, st, nodes, n, off);
+    return hipGetLastError();
+}
+
+hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], const double hi[3], int per_leaf, int max_levels, CwNode** cw, DTri** fast_tris,
+                             int* n_nodes, int* levels, int* n_top, std::vector<double>* top_boxes, double* absmax, hipStream_t st)
+{
+    *cw = nullptr; *fast_tris = nullptr; *n_nodes = 0; *levels = 0; *n_top = 0; *absmax = 0;
     if (t <= 0 || t > (1 << 27)) return hipErrorInvalidValue;                  // leaf references hold first << 4
     // ---- order: sort (63-bit Morton code, leaf index), gather the triangle records into that order
     DTri* tris = nullptr;
@@ -239,9 +253,9 @@ hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], c
         drop();
         if (rc != hipSuccess) { (void)hipFree(tris); return rc; }
     }
-    const int groups = (t + 3) / 4;
+    const int groups = (t + per_leaf - 1) / per_leaf;
     int size[16], L = 0;                                                       // size[d] = nodes of inner level d, bottom first
-    for (int n = groups;;) { n = (n + 3) / 4; size[L++] = n; if (n == 1) break; }
+    for (int n = groups;;) { n = (n + 3) / 4; size[L++] = n; if (n == 1 || L == max_levels) break; }   // stops below the root: a forest
     int total = 0;
     for (int d = 0; d < L; d++) total += size[d];
     FBox *a = nullptr, *b = nullptr;
@@ -254,14 +268,14 @@ hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], c
     if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&nodes), size_t(total) * sizeof(CwNode));
     if (rc == hipSuccess) rc = hipMemsetAsync(am, 0, sizeof(unsigned long long), st);
     if (rc != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(tris); return rc; }
-    hipLaunchKernelGGL(k_fast_leaf_boxes, dim3((groups + 255) / 256), dim3(256), 0, st, tris, t, groups, a, am);
+    hipLaunchKernelGGL(k_fast_leaf_boxes, dim3((groups + 255) / 256), dim3(256), 0, st, tris, t, per_leaf, groups, a, am);
     // root = node 0: level bases run top-down while the levels are built bottom-up
     int n_children = groups;
     for (int d = 0; d < L; d++) {
         int base = 0, child_base = 0;
         for (int u = L - 1; u > d; u--) base += size[u];
         child_base = base + size[d];                                           // the level below follows this one
-        hipLaunchKernelGGL(k_fast_level, dim3((size[d] + 255) / 256), dim3(256), 0, st, a, n_children, child_base, d == 0 ? 1 : 0, t, b, nodes, base,
+        hipLaunchKernelGGL(k_fast_level, dim3((size[d] + 255) / 256), dim3(256), 0, st, a, n_children, child_base, d == 0 ? per_leaf : 0, t, b, nodes, base,
                            size[d]);
         FBox* tmp = a; a = b; b = tmp;                                         // b (size[0] entries) is large enough for every later level
         n_children = size[d];
@@ -269,11 +283,17 @@ hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], c
     unsigned long long bits = 0;
     rc = hipGetLastError();
     if (rc == hipSuccess) rc = hipMemcpyAsync(&bits, am, sizeof bits, hipMemcpyDeviceToHost, st);
+    // exact boxes of the top level built here (nodes 0 .. size[L-1]-1): what the host's builder sees of each cluster; after the
+    // last swap they are in `a`
+    if (rc == hipSuccess && top_boxes) {
+        top_boxes->resize(size_t(size[L - 1]) * 6);
+        rc = hipMemcpyAsync(top_boxes->data(), a, size_t(size[L - 1]) * sizeof(FBox), hipMemcpyDeviceToHost, st);
+    }
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);
     cleanup();
     if (rc != hipSuccess) { (void)hipFree(nodes); (void)hipFree(tris); return rc; }
     double v; std::memcpy(&v, &bits, sizeof v);
-    *cw = nodes; *fast_tris = tris; *n_nodes = total; *levels = L; *absmax = v;
+    *cw = nodes; *fast_tris = tris; *n_nodes = total; *levels = L; *n_top = size[L - 1]; *absmax = v;
     return hipSuccess;
 }
 

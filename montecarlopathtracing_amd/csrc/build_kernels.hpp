@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <vector>
+
 #include "../../include/mcpt.h"
 #include "device_scene.hpp"
 
@@ -20,12 +22,15 @@ struct BuildInputs {            // faces in .obj order, device pointers
 // fills nodes[Nr] (compact level order), tris[t], shade[t] (leaf order) and d_order[t] (leaf -> .obj face)
 hipError_t device_build_reference(const BuildInputs& in, const mcpt_bvh_info& bi, DNode* nodes, DTri* tris, DTriShade* shade,
                                   int32_t* d_order, hipStream_t st);
-// The fast hierarchy on the device (MCPT_BUILD_DEVICE_FAST): the triangle records sorted by a 63-bit Morton code on the scene's
-// bounds [lo, hi], a complete 4-ary tree over groups of four consecutive ones, written as the compressed nodes the walk kernels
-// read.  Only ever used to cull (trace_fast.hpp), so its shape cannot change a result.  *cw and *fast_tris are hipMalloc'ed
-// here; levels = inner levels (the walk needs 3 * levels stack entries); absmax = largest |coordinate| of the scene.
-hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], const double hi[3], CwNode** cw, DTri** fast_tris, int* n_nodes,
-                             int* levels, double* absmax, hipStream_t st);
+// The lower part of the fast hierarchy on the device (MCPT_BUILD_DEVICE_FAST): the triangle records sorted by a 63-bit Morton
+// code on the scene's bounds [lo, hi] and a complete 4-ary tree over leaves of per_leaf consecutive ones, at most max_levels levels
+// high, written as the compressed nodes the walk kernels read.  With t <= 4^(max_levels+1) that is the whole tree (n_top = 1);
+// otherwise it is a forest of n_top clusters (nodes 0 .. n_top-1 are their roots, top_boxes their exact boxes, lo[3] hi[3] each)
+// for the host to put a SAH tree over (accel_build.cpp: build_fast_upper).  Only ever used to cull (trace_fast.hpp), so its
+// shape cannot change a result.  *cw and *fast_tris are hipMalloc'ed here; the walk needs 3 stack entries per level.
+hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], const double hi[3], int per_leaf, int max_levels, CwNode** cw, DTri** fast_tris,
+                             int* n_nodes, int* levels, int* n_top, std::vector<double>* top_boxes, double* absmax, hipStream_t st);
+hipError_t device_offset_children(CwNode* nodes, int n, int off, hipStream_t st);     // child >= 0 -> child + off
 hipError_t device_gather_tris(const DTri* tris, const int32_t* d_slots, int n, DTri* out, hipStream_t st);
 
 }  // namespace mcpt
