@@ -74,7 +74,11 @@ class Scene:
             lib().mcpt_scene_free(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass
 
     def set_resolution(self, width, height):
         check(lib().mcpt_scene_set_resolution(self._h, width, height))
@@ -168,7 +172,11 @@ class Device:
             lib().mcpt_device_free(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass
 
     def bvh_nodes(self):
         """(box6 [Nr,6], leaf_face [Nr]) read back from HBM."""
