@@ -9,7 +9,7 @@
 //     take the next slots of the range: the refill is a ballot + prefix count, no memory traffic.
 //   * Each lane is a small state machine: IDLE, INNER (about to test the two children of an inner node),
 //     TRI (walking the triangles of a leaf).  Per wave iteration the wave executes ONE phase -- the one most lanes are
-//     waiting for (majority vote over __ballot masks) -- so a phase always runs with at least a third of the lanes
+//     waiting for (vote over __ballot masks, slightly biased to the cheaper inner step) -- so a phase always runs with at least a third of the lanes
 //     that have work, instead of every phase running for whoever happens to need it.
 //   * Per-lane traversal stack in LDS ([depth][lane], conflict free); rays that need the reference-shaped walk
 //     (a zero / denormal / non-finite component) are not walked here: their slot goes to a side list that a second,
@@ -27,6 +27,13 @@ namespace mcpt {
 #endif
 #ifndef MCPT_TAIL_CHUNK
 #define MCPT_TAIL_CHUNK 256         /* slots per claim in the last eighth of a launch */
+#endif
+#ifndef MCPT_TRI_BIAS_NUM
+#define MCPT_TRI_BIAS_NUM 3         /* the triangle phase runs when NUM * (lanes waiting for it) > DEN * (lanes waiting for an */
+#endif                              /* inner step).  Sweep NUM/4 (ms per frame): 1: 113.2, 2: 110.1, 3: 108.7, 4 (plain majority): */
+                                    /* 110.5, 5: 111.4, 6: 112.2, 8: 115.1 -- the cheaper phase may run with a few lanes less */
+#ifndef MCPT_TRI_BIAS_DEN
+#define MCPT_TRI_BIAS_DEN 4
 #endif
 #ifndef MCPT_INNER_BURST
 #define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
@@ -174,8 +181,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
             w.diag[4] += 64 - __popcll(m_inner) - __popcll(m_tri);
         }
 #endif
-        MCPT_STAMP(__popcll(m_inner) >= __popcll(m_tri) ? 1 : 2)
-        if (__popcll(m_inner) >= __popcll(m_tri)) {
+        const bool run_inner = m_inner && MCPT_TRI_BIAS_DEN * __popcll(m_inner) >= MCPT_TRI_BIAS_NUM * __popcll(m_tri);
+        MCPT_STAMP(run_inner ? 1 : 2)
+        if (run_inner) {
             // -------------------------------------------------------------- inner steps (a short burst per vote)
 #pragma unroll 1
             for (int burst = 0; burst < MCPT_INNER_BURST; burst++)
