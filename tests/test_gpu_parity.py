@@ -187,6 +187,7 @@ def test_chunked_frame_equals_single_chunk(mcpt, monkeypatch):
     """By default the path state of a whole frame sits in HBM at once; with a 16-MB workspace the same frame takes dozens of
     chunks (and the small tail launches of each).  Same samples, same arithmetic: the same bits."""
     monkeypatch.setenv("MCPT_FINISH_PATHS", "500")        # keep the wavefront iterations going in the small chunks too
+    monkeypatch.delenv("MCPT_WORKSPACE_GB", raising=False)
     sc = mcpt.Scene(SCENES, "cornell-box", width=160, height=120)
     one = mcpt.Device(sc, 0)
     st1 = mcpt.Stats()
