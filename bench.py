@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="size of the CPU baseline's bounded sample")
     ap.add_argument("--save-png", default=None)
     ap.add_argument("--tris", type=int, default=10_000_000, help="--scene synthetic: number of lattice triangles")
     ap.add_argument("--build", default="default", choices=["default", "host", "device", "device_fast"],
@@ -266,7 +267,7 @@ def main():
             img = frame.cpu().numpy()
             M.write_png(args.save_png, M.imshow_rgb8(img))
         if world == 1 and not args.no_cpu_baseline and scene_dir is not None and args.scene != "interior":
-            cb = cpu_baseline(scene_dir, args.scene, args.seed)
+            cb = cpu_baseline(scene_dir, args.scene, args.seed, args.cpu_seconds)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu_mrays"] = value / cb["value"]
             # frame-time ratio: CPU seconds for the full frame extrapolated linearly in samples
