@@ -459,3 +459,38 @@ def test_bench_line_keeps_its_contract(tmp_path):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
+
+
+@pytest.mark.parametrize("name,spp", [("cornell-box", 256), ("veach-mis", 100)])
+def test_full_size_frame_properties(mcpt, monkeypatch, name, spp):
+    """BASELINE's own frames (configs 2 and 3: cornell-box 1280x720 SPP 256, veach-mis SPP 100), which the oracle cannot finish in seconds, through properties that do
+    not depend on size: rendering it again gives the same bits; the 8-rank tile partition assembles to the same bits; a frame
+    cut into chunks by a small workspace gives the same bits; its mean agrees with an independent seed's within Monte-Carlo
+    error; every ray the statistics count was traced (samples = pixels x SPP, rays = shadow + bounce)."""
+    import bench
+    d = bench.write_scene_dir(name, 1280, 720)
+    monkeypatch.delenv("MCPT_WORKSPACE_GB", raising=False)
+    sc = mcpt.Scene(d, name)
+    dev = mcpt.Device(sc, 0)
+    st = mcpt.Stats()
+    full = dev.generateImg(spp, seed=0, stats=st)
+    again = dev.generateImg(spp, seed=0)
+    assert np.array_equal(_bits(full), _bits(again))
+    assert st.samples == 1280 * 720 * spp and st.rays_primary == 1280 * 720
+    assert st.rays_shadow > 0 and st.rays_bounce > 0 and st.shade_calls >= st.rays_bounce * 0.9
+    parts = np.zeros_like(full)
+    for r in range(8):
+        dev.generateImg(spp, seed=0, rank=r, world=8, img=parts)
+    assert np.array_equal(_bits(full), _bits(parts))
+    other = dev.generateImg(spp, seed=12345)
+    assert not np.array_equal(_bits(full), _bits(other))
+    assert abs(other.mean() - full.mean()) < 5e-3 * full.mean()
+    dev.close()
+    monkeypatch.setenv("MCPT_WORKSPACE_GB", "6")               # 6 GB of path state: about 14 chunks
+    small = mcpt.Device(sc, 0)
+    st2 = mcpt.Stats()
+    chunked = small.generateImg(spp, seed=0, stats=st2)
+    assert st2.launches > 2 * st.launches
+    assert np.array_equal(_bits(full), _bits(chunked))
+    small.close()
+    sc.close()
