@@ -87,6 +87,7 @@ struct mcpt_device {
     size_t wf_auto_budget = 0;                      // that half, asked for once (hipMemGetInfo costs a few hundred microseconds)
     void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
     int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
+    PrimarySurface* surf = nullptr; int64_t surf_cap = 0;   // first-vertex record per hit pixel of the chunk
     WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // start/stop pairs around trace launches
     TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
@@ -399,7 +400,7 @@ void mcpt_device_free(mcpt_device* d)
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
     void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes, d->d_order,
-                    d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->wf_counts, d->queue, d->slow_list};
+                    d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->surf, d->wf_counts, d->queue, d->slow_list};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pr : d->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -849,10 +850,11 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
     }
     int rc = grow(&d->hit_slots, &d->hit_slots_cap, chunk_slots);
     if (rc) return rc;
+    if ((rc = grow(&d->surf, &d->surf_cap, chunk_slots))) return rc;
     WfArgs a{};
     WfState A, B;
     if (!wf_carve(d->wf_ws, d->wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
-    a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = d->hit_slots; a.hits = d->hits;
+    a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = d->hit_slots; a.surf = d->surf; a.hits = d->hits;
     a.dirs = d->dirs; a.rad = d->rad; a.counts = d->wf_counts; a.ctr = d->ctr; a.tris = d->tris;
     a.finish_below = fast ? unsigned(std::min<long long>(std::max<long long>(d->finish_threshold, 0), 1ll << 30)) : 0u;
     // Iterations are enqueued without waiting for their counts: every kernel reads its input count from the device slot the
@@ -878,6 +880,9 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
         double n_grid = double(n_upper);                     // grid-sizing estimate between looks (kernels stride, any grid is correct)
         a.first_slot = int(first);
         a.in = A; a.out = B;
+        a.counts_in = &d->wf_counts[0];
+        launch_primary_surface(d->ds, a, d->surf, n_slots, st);      // what the samples of a pixel share at their first vertex
+        HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < MCPT_MAX_DEPTH && n_upper > 0; depth++) {
             a.depth = depth;
             a.counts_in = &d->wf_counts[depth]; a.count_mul = depth == 0 ? unsigned(spp) : 1u;

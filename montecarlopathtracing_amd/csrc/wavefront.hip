@@ -81,18 +81,16 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
 #endif
         const long long i = base + threadIdx.x;
         bool alive = false;
-        int id = 0, leaf = -1, in_type = RT_TRANSMISSION;
-        V3 p = mk(0, 0, 0), dir = mk(0, 0, 0), T = mk(1, 1, 1), L = mk(0, 0, 0);
+        int id = 0, leaf = -1, in_type = RT_TRANSMISSION, mat_first = 0, pix_first = 0;
+        V3 p = mk(0, 0, 0), dir = mk(0, 0, 0), T = mk(1, 1, 1), L = mk(0, 0, 0), pn_first = mk(0, 0, 0), kd_first = mk(0, 0, 0);
         if (i < n_prev) {
             bool have_vertex;
             if constexpr (FIRST) {
-                const int slot = a.hit_slots[i / a.spp];
+                const PrimarySurface* ps = a.surf + i / a.spp;          // the same record for all samples of a pixel
                 const int k = (int)(i % a.spp);
-                id = (slot - a.first_slot) * a.spp + k;
-                const PrimaryHit ph = a.hits[slot];
-                const int pix = a.pixels ? a.pixels[slot] : slot;
-                leaf = ph.leaf; p = mk(ph.p[0], ph.p[1], ph.p[2]);
-                dir = neg(ld3(a.dirs + (size_t)pix * 3));
+                id = (ps->slot - a.first_slot) * a.spp + k;
+                leaf = ps->leaf; mat_first = ps->material; pix_first = ps->pixel;
+                p = ld3(ps->p); dir = ld3(ps->dir); pn_first = ld3(ps->pn); kd_first = ld3(ps->kd);
                 have_vertex = true;
                 ls.samples = 1;
             } else {
@@ -132,7 +130,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             if (have_vertex) {
                 ls.shades++;
                 if (depth > ls.depth) ls.depth = depth;
-                const DMaterial* m = S.materials + S.tris[leaf].material;
+                const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
                 if (m->light >= 0) {                                             // emitter: pathTracing.cpp:141-144
                     const V3 rad = ld3(S.lights[m->light].radiance);
                     if (FIRST) L = rad;
@@ -160,14 +158,15 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         const long long j = off;
 
         // ---- shade vertex `depth` at position j (pathTracing.cpp:147-241; the pieces are in vertex.hpp)
-        const DMaterial* m = S.materials + S.tris[leaf].material;
-        V3 pn, kd;
-        vertex_surface(S, leaf, p, m, pn, kd);
+        const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
+        V3 pn = pn_first, kd = kd_first;
+        if (!FIRST) vertex_surface(S, leaf, p, m, pn, kd);
 
-        const int slot = a.first_slot + id / a.spp;
         RngKey key;
         key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
-        key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); key.sample = (uint32_t)(id % a.spp);
+        if (FIRST) key.pixel = (uint32_t)pix_first;
+        else { const int slot = a.first_slot + id / a.spp; key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); }
+        key.sample = (uint32_t)(id % a.spp);
 
         int sample_mat = -1;
         for (int l = 0; l < nl; l++) {
@@ -476,6 +475,27 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
     flush_stats(a.ctr, ls);
 }
 
+// one PrimarySurface per hit pixel of the chunk (same arithmetic as the per-sample code it replaces: vertex_surface)
+__global__ void k_primary_surface(DScene S, WfArgs a, PrimarySurface* __restrict__ surf)
+{
+    const unsigned int n = a.counts_in->n_next;
+    for (unsigned int h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
+        const int slot = a.hit_slots[h];
+        const PrimaryHit ph = a.hits[slot];
+        const int pix = a.pixels ? a.pixels[slot] : slot;
+        PrimarySurface r;
+        const V3 p = mk(ph.p[0], ph.p[1], ph.p[2]), dir = neg(ld3(a.dirs + (size_t)pix * 3));
+        r.p[0] = p.x; r.p[1] = p.y; r.p[2] = p.z; r.dir[0] = dir.x; r.dir[1] = dir.y; r.dir[2] = dir.z;
+        r.leaf = ph.leaf; r.material = S.tris[ph.leaf].material; r.pixel = pix; r.slot = slot;
+        V3 pn = mk(0, 0, 0), kd = mk(0, 0, 0);
+        const DMaterial* m = S.materials + r.material;
+        if (m->light < 0) vertex_surface(S, ph.leaf, p, m, pn, kd);
+        r.pn[0] = pn.x; r.pn[1] = pn.y; r.pn[2] = pn.z; r.kd[0] = kd.x; r.kd[1] = kd.y; r.kd[2] = kd.z;
+        surf[h] = r;
+    }
+}
+
+
 // slots of this chunk whose primary ray hit something, in slot order within a wave
 __global__ void k_hit_slots(const PrimaryHit* __restrict__ hits, int first_slot, int n_slots, int32_t* __restrict__ hit_slots, unsigned int* count)
 {
@@ -500,6 +520,12 @@ static unsigned grid_for(long long n, int block, unsigned cap_blocks)
     long long b = (n + block - 1) / block;
     if (b < 1) b = 1;
     return (unsigned)(b > cap_blocks ? cap_blocks : b);
+}
+
+void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, int n_slots_upper, hipStream_t st)
+{
+    if (n_slots_upper <= 0) return;
+    hipLaunchKernelGGL(k_primary_surface, dim3(grid_for(n_slots_upper, 256, 4096)), dim3(256), 0, st, S, a, surf);
 }
 
 int persistent_grid(const void* kernel);

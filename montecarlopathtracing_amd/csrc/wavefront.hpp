@@ -40,6 +40,14 @@ struct WfRays {
     double* d;              // [nl][3][cap] shadow-ray directions
 };
 
+// What all samples of a pixel share at their first vertex (the primary ray has no jitter): computed once per hit pixel by
+// k_primary_surface, read by the first logic pass as broadcast 16-byte loads instead of ~40 scattered ones per sample.
+struct alignas(16) PrimarySurface {
+    double p[3], dir[3];        // hit point, direction back to the eye
+    double pn[3], kd[3];        // interpolated normal and diffuse colour there (unset on an emitter)
+    int32_t leaf, material, pixel, slot;
+};
+
 struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
     unsigned long long head;        // next ticket (trace_persistent.hpp maps tickets to ray slots)
     unsigned int slow_count;        // rays deferred to the reference-shaped walk (may exceed the list capacity)
@@ -60,6 +68,7 @@ struct WfArgs {
     unsigned long long seed;
     const int32_t* pixels;      // slot -> pixel index (NULL: identity)
     const int32_t* hit_slots;   // first pass: compacted list of slots whose primary ray hit something
+    const PrimarySurface* surf; // first pass: one record per entry of hit_slots
     const PrimaryHit* hits;     // first pass: primary hit per slot
     const double* dirs;         // primary directions per pixel
     int first_slot;
@@ -86,6 +95,7 @@ void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipSt
 int persistent_grid(const void* kernel);
 long long persistent_chunk(long long total, int grid_blocks);
 
+void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, int n_slots_upper, hipStream_t st);
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st);
 void launch_zero_rad(double* rad, long long n_doubles, hipStream_t st);
 
