@@ -12,8 +12,8 @@
 namespace mcpt {
 
 #ifndef MCPT_LOGIC_WAVES
-#define MCPT_LOGIC_WAVES 4   /* waves per SIMD the logic kernel is compiled for: 128 VGPRs and 164 B of spills, but the kernel waits on
-                               memory (sweep, ms per frame: 2: 111.5, 3: 108.0, 4: 107.2, 5: 113.5, 6: 121.2) */
+#define MCPT_LOGIC_WAVES 3   /* waves per SIMD the logic kernel is compiled for (sweep, ms per frame: 2: 111.5, 3: 108.0, 4: 107.2 but
+                               1 % slower on veach-mis and the interior, 5: 113.5, 6: 121.2) */
 #endif
 
 // ---------------------------------------------------------------------------------------------- layout helpers
