@@ -94,6 +94,7 @@ struct orc_scene {
     orc_bvh_info bi;
     Node* nodes;
     double area0;            /* total area of light 0: the frozen range of the static u1 (Q1) */
+    int walk_mode;           /* ORC_TRACE_* the integrator's rays are walked with (same hits; ALIAS = the reference's visit counts) */
 };
 
 /* ------------------------------------------------------------------ RNG seam (D1) */
@@ -542,6 +543,35 @@ void orc_scene_free(orc_scene* s)
 }
 
 void orc_scene_set_resolution(orc_scene* s, int w, int h) { s->width = w; s->height = h; }
+void orc_scene_set_walk_mode(orc_scene* s, int mode) { s->walk_mode = mode; }
+
+/* Rebuilds the BVH over another order of the leaves that share a Morton key (D2): ORC_ORDER_STABLE = .obj order (the
+ * oracle's default), ORC_ORDER_LIBSTDCXX = what std::sort (MTPC/MTPC.cpp:44) leaves in a g++/libstdc++ build. */
+extern void orc_std_sort_order(const uint32_t* keys, int n, int32_t* order);
+int orc_scene_set_leaf_order(orc_scene* s, int which)
+{
+    char err[128];
+    uint32_t* keys = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)s->nf);
+    for (int i = 0; i < s->nf; i++) keys[i] = s->f[i].morton;
+    if (which == ORC_ORDER_LIBSTDCXX) orc_std_sort_order(keys, s->nf, s->order);
+    else {                                                   /* stable: (key, index) ascending */
+        int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * (size_t)s->nf);
+        orc_std_sort_order(keys, s->nf, tmp);                /* any key-sorted permutation, then equal keys by index */
+        int i = 0;
+        while (i < s->nf) {
+            int j = i;
+            while (j < s->nf && keys[tmp[j]] == keys[tmp[i]]) j++;
+            for (int a = i + 1; a < j; a++) { int32_t v = tmp[a]; int b = a - 1; while (b >= i && tmp[b] > v) { tmp[b + 1] = tmp[b]; b--; } tmp[b + 1] = v; }
+            i = j;
+        }
+        for (int k = 0; k < s->nf; k++) s->order[k] = tmp[k];
+        free(tmp);
+    }
+    free(keys);
+    for (int k = 1; k < s->nf; k++) if (s->f[s->order[k - 1]].morton > s->f[s->order[k]].morton) return -1;
+    free(s->nodes); s->nodes = NULL;
+    return build_bvh(s, err, sizeof err);
+}
 int orc_num_faces(const orc_scene* s) { return s->nf; }
 int orc_num_materials(const orc_scene* s) { return s->nm; }
 int orc_num_lights(const orc_scene* s) { return s->nl; }
@@ -885,7 +915,7 @@ static vec3 shade(Ctx* c, const Hit* p, vec3 dir, int depth)
         double visibility = 1;
         RayT rl = { vadd(p->p, vmul(direction, 0.01)), direction };
         Hit inter;
-        ray_intersect(s, &rl, &inter, ORC_TRACE_REAL_ONLY, &c->c);
+        ray_intersect(s, &rl, &inter, s->walk_mode, &c->c);
         if (c->st) c->st->rays_shadow++;
         int inter_mat = inter.hit ? s->f[s->order[inter.leaf]].material : -1;
         if (inter_mat != sample_mat) visibility = 0;                           /* :213 */
@@ -912,7 +942,7 @@ static vec3 shade(Ctx* c, const Hit* p, vec3 dir, int depth)
         RayT rr = { r.o, r.d };
         Hit ret;
         if (c->st) c->st->rays_bounce++;
-        if (ray_intersect(s, &rr, &ret, ORC_TRACE_REAL_ONLY, &c->c)) {
+        if (ray_intersect(s, &rr, &ret, s->walk_mode, &c->c)) {
             vec3 intensity = vdiv(shade(c, &ret, vneg(r.d), depth + 1), P_RR);
             if (r.type == RT_DIFFUSE) {
                 const Material* hm = &s->m[s->f[s->order[ret.leaf]].material];
@@ -971,11 +1001,27 @@ void orc_primary_ray(const orc_scene* s, int row, int col, double ray6[6])
     ray6[0] = cf.eye.x; ray6[1] = cf.eye.y; ray6[2] = cf.eye.z; ray6[3] = d.x; ray6[4] = d.y; ray6[5] = d.z;
 }
 
+/* the primary rays of rows [row0,row1), every column, in generateImg's own order (one running sum per row) */
+void orc_primary_rays(const orc_scene* s, int row0, int row1, double* rays6)
+{
+    CamFrame cf = cam_frame(s);
+    const int W = s->width;
+    for (int i = row0; i < row1; i++) {
+        vec3 pos = vsub(cf.start_point, vmul(cf.screen_pdy, i));        /* :297 */
+        for (int j = 0; j < W; j++) {
+            vec3 d = vnormalize(vsub(pos, cf.eye));                     /* :306-308 */
+            double* r = rays6 + ((size_t)(i - row0) * W + j) * 6;
+            r[0] = cf.eye.x; r[1] = cf.eye.y; r[2] = cf.eye.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+            pos = vadd(pos, cf.screen_pdx);                             /* :326 */
+        }
+    }
+}
+
 static vec3 sample_radiance(Ctx* c, const RayT* ray, const Hit* primary, int have_primary)
 {
     Hit h;
     if (have_primary) h = *primary;
-    else { if (c->st) c->st->rays_primary++; ray_intersect(c->s, ray, &h, ORC_TRACE_REAL_ONLY, &c->c); }
+    else { if (c->st) c->st->rays_primary++; ray_intersect(c->s, ray, &h, c->s->walk_mode, &c->c); }
     if (c->st) c->st->samples++;
     if (!h.hit) return v3(0, 0, 0);
     return shade(c, &h, vneg(ray->d), 0);
@@ -1023,7 +1069,7 @@ void orc_render(const orc_scene* s, int spp, uint64_t seed, int row0, int row1, 
                     Hit primary; int have = 0;
                     if (!faithful_cost) {                              /* identical for every k: trace once */
                         local.rays_primary++;
-                        ray_intersect(s, &ray, &primary, ORC_TRACE_REAL_ONLY, &c.c);
+                        ray_intersect(s, &ray, &primary, s->walk_mode, &c.c);
                         have = 1;
                     }
                     for (int k = 0; k < spp; k++) {

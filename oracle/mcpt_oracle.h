@@ -9,15 +9,25 @@
  * reference checkout, e.g. MTPC/pathTracing.cpp:137).  All arithmetic is IEEE fp64
  * in the reference's own operation order, compiled with -ffp-contract=off.
  *
- * Pinning status (see DESIGN.md "Oracle"):
+ * Pinning status (see DESIGN.md "Oracle"; tests/test_oracle_pins.py, tests/pins_common.py):
  *   - Morton keys      : pinned bit-exactly against the reference's own "morton code.cpp"
  *                        compiled from where it lies (oracle/_ref/libref_morton.so).
  *   - PNG bytes        : pinned byte-exactly against the reference's svpng.inc (oracle/_ref).
- *   - loader/BVH/traversal/shading: the reference TUs need glm, OpenCV and Eigen headers
- *     that this image lacks, so they are unbuildable here; the reference ships no tests or
- *     golden vectors.  The only reference outputs are the time-seeded renders under
- *     result/ *.png; the oracle is pinned STATISTICALLY against block means of those
- *     (tests/golden/published_*.npz).  Bitwise parity of those stages: PARITY UNPINNED.
+ *   - camera model, loader, Morton order/BVH, primary closest hit: pinned PIXEL-EXACTLY by the
+ *     RNG-independent pixels of the reference's published renders (a primary hit on an emitter is
+ *     (255,255,255) whatever the RNG did): 4 922 / 4 922 pixels of cornell-box in six renders, with
+ *     only 4 other saturated pixels in cornell-box-SPP25.png; 45 266 / 45 266 of veach-mis.
+ *   - traversal + shading as a whole: (a) the work they do equals, figure for figure, what SURVEY.md
+ *     3.5 measured on an instrumented build of the reference itself (rays per sample by kind, shade
+ *     calls, box tests per ray to 4 digits: 264.26 vs 264.2 on veach-mis, triangle tests per ray),
+ *     once the walk aliases virtual children like the reference (Q7) and the leaves are ordered as
+ *     libstdc++'s unstable std::sort leaves them (std_sort_order.cpp); (b) the pictures agree with
+ *     the published renders of the matching revision at MONTE-CARLO PRECISION: per-16x16-block
+ *     z-scores at native resolution and the published SPP are standard normal (cornell-box SPP 25:
+ *     mean -0.02, rms 0.99; whole-picture brightness within 0.05 %; veach-mis SPP 10 and 100).
+ *   - bitwise values of traversal / shading: the reference TUs need glm, OpenCV and Eigen headers
+ *     that this image lacks (no stand-ins are written) and the reference ships no tests or golden
+ *     vectors, so beyond the above: PARITY UNPINNED.
  *
  * Documented deviations from the reference (all needed for reproducibility / to avoid UB):
  *   D1  RNG seam: the four time(NULL)-seeded static engines (pathTracing.cpp:5,32,68,169)
@@ -70,6 +80,13 @@ uint32_t orc_morton_code(float x, float y, float z);
 orc_scene* orc_scene_load(const char* prefix, const char* texture_dir, char* err, int errlen);
 void       orc_scene_free(orc_scene*);
 void       orc_scene_set_resolution(orc_scene*, int width, int height);
+/* which walk (ORC_TRACE_*, below) orc_render / orc_sample_radiance use for their rays; default ORC_TRACE_REAL_ONLY.
+ * ORC_TRACE_ALIAS gives the same picture with the reference's own node-visit counts (Q7). */
+void       orc_scene_set_walk_mode(orc_scene*, int mode);
+/* D2: rebuild the BVH with another order of the faces that share a Morton key.  0 on success. */
+#define ORC_ORDER_STABLE    0   /* .obj order among equal keys (default) */
+#define ORC_ORDER_LIBSTDCXX 1   /* the order std::sort (MTPC/MTPC.cpp:44) leaves in a g++/libstdc++ build (std_sort_order.cpp) */
+int        orc_scene_set_leaf_order(orc_scene*, int which);
 
 int  orc_num_faces(const orc_scene*);
 int  orc_num_materials(const orc_scene*);
@@ -100,6 +117,8 @@ void orc_trace_closest(const orc_scene*, const double* rays, int64_t n, int mode
 void orc_sample_radiance(const orc_scene*, uint64_t seed, int row, int col, int k, double rgb[3], orc_stats* st);
 /* primary ray for a pixel, exactly as generateImg builds it (incl. the running-sum position) */
 void orc_primary_ray(const orc_scene*, int row, int col, double ray6[6]);
+/* rows [row0,row1) x all columns, (row1-row0)*W x 6 doubles */
+void orc_primary_rays(const orc_scene*, int row0, int row1, double* rays6);
 /* render rows [row0,row1) x cols [col0,col1) into img (full H*W*3 layout, doubles; other pixels untouched).
  * faithful_cost!=0 re-traces the primary ray and rebuilds light CDFs per call like the reference
  * (same result, reference-like cost; used for the CPU baseline).  nthreads<=0 -> OpenMP default. */

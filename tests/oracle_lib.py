@@ -14,6 +14,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 SCENES = os.path.join(ROOT, "scenes")
 
 TRACE_REAL_ONLY, TRACE_ALIAS, TRACE_FLAT = 0, 1, 2
+ORDER_STABLE, ORDER_LIBSTDCXX = 0, 1
 
 
 class BvhInfo(C.Structure):
@@ -36,7 +37,7 @@ def _ptr(a, t):
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "libmcpt_oracle.so")
     src = os.path.join(ORACLE_DIR, "mcpt_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ORACLE_DIR, "std_sort_order.cpp"))):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libmcpt_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -52,6 +53,8 @@ def lib():
         L.orc_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.orc_scene_free.argtypes = [C.c_void_p]
         L.orc_scene_set_resolution.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_scene_set_walk_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_scene_set_leaf_order.argtypes = [C.c_void_p, C.c_int]
         for f in ("orc_num_faces", "orc_num_materials", "orc_num_lights"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.orc_get_camera.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -69,6 +72,7 @@ def lib():
         L.orc_sample_radiance.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                           C.POINTER(Stats)]
         L.orc_primary_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.orc_primary_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_double), C.POINTER(Stats)]
         L.orc_render_strided.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -116,6 +120,13 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def set_walk_mode(self, mode):
+        lib().orc_scene_set_walk_mode(self.h, mode)
+
+    def set_leaf_order(self, which):
+        if lib().orc_scene_set_leaf_order(self.h, which) != 0:
+            raise RuntimeError("oracle: leaf order rebuild failed")
 
     def faces(self):
         n = self.num_faces
@@ -172,6 +183,13 @@ class OracleScene:
     def primary_ray(self, row, col):
         r = np.zeros(6)
         lib().orc_primary_ray(self.h, row, col, _ptr(r, C.c_double))
+        return r
+
+    def primary_rays(self, row0=0, row1=None):
+        """primary rays of rows [row0,row1), all columns: [(row1-row0)*W, 6]"""
+        row1 = self.height if row1 is None else row1
+        r = np.zeros(((row1 - row0) * self.width, 6))
+        lib().orc_primary_rays(self.h, row0, row1, _ptr(r, C.c_double))
         return r
 
     def sample_radiance(self, seed, row, col, k, stats=None):

@@ -204,33 +204,70 @@ def test_chunked_frame_equals_single_chunk(mcpt, monkeypatch):
     assert (st1.rays_shadow + st1.shadow_skipped, st1.rays_bounce, st1.shade_calls) == (st2.rays_shadow + st2.shadow_skipped, st2.rays_bounce, st2.shade_calls)
 
 
-def _blocks(img8, b):
-    h, w, _ = img8.shape
-    hh, ww = (h // b) * b, (w // b) * b
-    return img8[:hh, :ww].astype(np.float32).reshape(hh // b, b, ww // b, b, 3).mean(axis=(1, 3))
+@pytest.mark.parametrize("finish_paths", ["0", "500"])
+@pytest.mark.parametrize("mode", ["fast", "reference"])
+def test_wavefront_iterations_against_megakernel_and_oracle(pair, oracle, mcpt, monkeypatch, finish_paths, mode):
+    """The path the full-size frames take: with the hand-over to k_wf_finish switched off (0) or pushed to the last 500 paths,
+    every bounce of the 160x90 frames runs k_wf_logic<false> (resolve + shade), WfRaySource fetch/store in k_wf_trace (fast) or
+    k_wf_trace_reference, the T/L folding of the one-light case and the unfolded state of the several-light scenes.  Held to
+    the megakernel (one lane per sample, reference-shaped walk) bit for bit and to the oracle inside the flip budget.
+    MCPT_FINISH_PATHS is read when the device is created, hence a device of its own."""
+    name, osc, sc, dev0 = pair
+    monkeypatch.setenv("MCPT_FINISH_PATHS", finish_paths)
+    dev = mcpt.Device(sc, 0)
+    try:
+        dev.set_trace_mode(mcpt.TRACE_REFERENCE if mode == "reference" else mcpt.TRACE_FAST)
+        spp = 8
+        st = mcpt.Stats()
+        a = dev.generateImg(spp, seed=3, stats=st)
+        b = dev.generateImg(spp, seed=3, flags=mcpt.RENDER_MEGAKERNEL)
+        assert np.array_equal(_bits(a), _bits(b)), "%d channels differ from the megakernel" % int((_bits(a) != _bits(b)).sum())
+        assert st.launches >= 8, st.launches                  # the bounce loop really ran as wavefront iterations
+        if mode == "fast" and finish_paths == "0":
+            assert st.dom_rays > 0.9 * (st.rays_shadow + st.rays_bounce)     # ... and its rays went through k_wf_trace
+        ref = osc.render(spp, seed=3)
+        rel = np.abs(a - ref) / np.maximum(np.abs(ref), 1e-6)
+        bad = int((rel > 1e-6).sum())
+        assert bad <= max(3, int(a.size * spp * FLIP_BUDGET[name] * 0.5)), "%d pixel channels differ from the oracle" % bad
+    finally:
+        dev.close()
 
 
-def test_published_renders_full_resolution(mcpt):
-    """The reference's own published renders (time-seeded, so statistical): full native resolution and the published SPP
-    on the GPU, 16x16-block means against tests/golden/published_renders.npz."""
-    g = np.load(os.path.join(ROOT, "tests", "golden", "published_renders.npz"))
+def _gpu_emitter_map(mcpt, sc, dev):
+    """[H, W] bool from the product's own frame: at SPP 1 a pixel whose primary hit is an emitter holds the light's radiance
+    exactly (pathTracing.cpp:141-144; k_primary_dirs -> primary hits -> k_wf_logic<true>), nothing else does."""
+    img = dev.generateImg(1, seed=1)
+    emit = np.zeros(img.shape[:2], dtype=bool)
+    for l in range(sc.info.num_lights):
+        emit |= (img == sc.light(l)[1][None, None, :]).all(axis=2)
+    return emit
+
+
+def test_published_renders_pin_the_gpu_path(mcpt):
+    """What the reference's published renders pin (tests/pins_common.py), applied to the HIP path at native resolution:
+    (1) pixel-exact: every pixel whose primary hit is an emitter is (255,255,255) in every published render of the scene --
+    4 922 pixels of cornell-box (and only 4 other pixels of cornell-box-SPP25.png are saturated), 45 266 of veach-mis;
+    (2) Monte-Carlo precision: z-scores of all 16x16 blocks against two GPU renders at the published SPP are standard normal."""
+    import pins_common as P
     sc = mcpt.Scene(SCENES, "cornell-box")                  # native 1024x1024 camera
     dev = mcpt.Device(sc, 0)
-    mine = _blocks(mcpt.imshow_rgb8(dev.generateImg(25, seed=1)), 16)
-    pub = g["cornell_spp25"]
-    assert abs(mine.mean() - pub.mean()) < 0.01 * pub.mean(), (mine.mean(), pub.mean())
-    assert np.corrcoef(mine.ravel(), pub.ravel())[0, 1] > 0.99
-    assert np.sqrt(((mine - pub) ** 2).mean()) < 6.0
+    got = P.check_emitter_pixels(_gpu_emitter_map(mcpt, sc, dev), "cornell-box")
+    assert all(v[0] == 4922 for v in got.values()) and got["cornell_spp25"][1] == 4, got
+    qa, qb = (mcpt.imshow_rgb8(dev.generateImg(25, seed=s)) for s in (101, 102))
+    diff, sigma = P.block_stats("cornell_spp25", qa, qb)
+    assert diff.shape == (4096, 3)
+    print(P.assert_standard_normal(diff, sigma, "cornell-box SPP25, all blocks", mean_tol=0.1, rms=(0.9, 1.12)))
     dev.close()
     sc.close()
     sc = mcpt.Scene(SCENES, "veach-mis")                    # native 1200x900
     dev = mcpt.Device(sc, 0)
-    img = mcpt.imshow_rgb8(dev.generateImg(100, seed=1))
-    mine = _blocks(img[:896], 16)
-    pub = g["veach_spp100"]
-    assert mine.shape == pub.shape
-    assert abs(mine.mean() - pub.mean()) < 0.01 * pub.mean(), (mine.mean(), pub.mean())
-    assert np.corrcoef(mine.ravel(), pub.ravel())[0, 1] > 0.99
+    got = P.check_emitter_pixels(_gpu_emitter_map(mcpt, sc, dev), "veach-mis")
+    assert got["veach_spp10"][0] == 45266 and got["veach_spp100"][0] == 45266, got
+    for name, spp in (("veach_spp10", 10), ("veach_spp100", 100)):
+        qa, qb = (mcpt.imshow_rgb8(dev.generateImg(spp, seed=s)) for s in (201, 202))
+        diff, sigma = P.block_stats(name, qa, qb)
+        print(P.assert_standard_normal(diff, sigma, "veach-mis %s, all unsaturated blocks" % name, mean_tol=0.3, rms=(0.8, 1.45), tail=0.02,
+                                       drop_saturated=True))
     dev.close()
     sc.close()
 

@@ -4,8 +4,10 @@
   * Morton keys against the reference's own "morton code.cpp" (compiled where it lies into oracle/_ref, plus the
     committed vectors generated from it: tests/golden/morton_vectors.npz);
   * PNG bytes against the reference's own svpng.inc (oracle/_ref + committed files);
-  * the integrator as a whole against the renders the reference publishes (result/*.png block means): statistical,
-    because those runs are time-seeded -- bitwise parity of traversal/shading is UNPINNED.
+  * the renders the reference publishes (result/*.png), see pins_common.py: their RNG-independent pixels (primary hits on
+    emitters) pin camera model, loader, Morton/BVH and primary closest hit PIXEL-EXACTLY; everything random is held to them
+    at Monte-Carlo precision (per-block z-scores at native resolution and the published SPP).  Bitwise values of
+    traversal/shading beyond that remain UNPINNED (the reference TUs cannot be compiled here).
 """
 import ctypes as C
 import os
@@ -13,6 +15,7 @@ import os
 import numpy as np
 import pytest
 
+import pins_common as P
 from conftest import ROOT, SCENES
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -86,37 +89,153 @@ def test_quantize_is_truncating_clamp(oracle):
     assert oracle.quantize(v).tolist() == [0, 0, 0, 0, 1, 127, 255, 255, 254, 255]
 
 
-def _blocks(img8, b):
-    h, w, _ = img8.shape
-    hh, ww = (h // b) * b, (w // b) * b
-    return img8[:hh, :ww].astype(np.float32).reshape(hh // b, b, ww // b, b, 3).mean(axis=(1, 3))
+def _emitter_map(oracle, s):
+    """[H, W] bool: the oracle's primary hit at native resolution is on a light material (pathTracing.cpp:141-144)"""
+    face, _, _, _ = s.trace_closest(s.primary_rays())
+    _, mat, _ = s.faces()
+    is_light = np.array([s.material(i)[2][3] >= 0 for i in range(s.num_materials)])
+    return ((face >= 0) & is_light[mat[np.maximum(face, 0)]]).reshape(s.height, s.width)
 
 
-def test_cornell_matches_published_render_statistically(oracle):
-    """The shipped main() renders cornell-box at SPP 25 (MTPC/MTPC.cpp:78); result/cornell-box-SPP25.png is that run.
-    The oracle at a quarter of the resolution (same field of view) must reproduce its 16x16-block means."""
-    pub = np.load(os.path.join(GOLD, "published_renders.npz"))["cornell_spp25"]      # [64,64,3], 0..255
-    s = oracle.OracleScene(SCENES + "cornell-box", texture_dir=SCENES, width=256, height=256)
-    img = s.render(25, seed=2025)
-    mine = _blocks(oracle.quantize(img), 4)
-    assert mine.shape == pub.shape
-    assert abs(mine.mean() - pub.mean()) < 0.012 * pub.mean(), (mine.mean(), pub.mean())
-    assert np.corrcoef(mine.ravel(), pub.ravel())[0, 1] > 0.975
-    for name, (rs, cs) in {"ceiling": (slice(1, 6), slice(8, 22)), "back wall": (slice(12, 30), slice(12, 52)),
-                           "floor": (slice(58, 63), slice(12, 52)), "left wall": (slice(10, 50), slice(1, 6)),
-                           "right wall": (slice(10, 50), slice(58, 63)), "furniture": (slice(36, 54), slice(14, 50))}.items():
-        a, b = mine[rs, cs].mean(), pub[rs, cs].mean()
-        assert abs(a - b) < 0.05 * b + 0.5, (name, a, b)
+def test_cornell_emitter_pixels_are_the_saturated_pixels_of_the_published_renders(oracle):
+    """Pixel-exact pin (pins_common.py): all 4 922 pixels whose primary hit is the light are (255,255,255) in every
+    published cornell-box render (result/cornell-box-SPP256.png, an aborted run with 25 rows, is left out), and in
+    cornell-box-SPP25.png -- the run the shipped main() makes -- exactly 4 other pixels are, all far from the light."""
+    s = oracle.OracleScene(SCENES + "cornell-box", texture_dir=SCENES)
+    assert (s.width, s.height) == (1024, 1024)
+    emit = _emitter_map(oracle, s)
+    got = P.check_emitter_pixels(emit, "cornell-box")
+    assert set(got) == {"cornell_spp2", "cornell_spp2_result", "cornell_spp16", "cornell_spp25", "cornell_spp50", "cornell_spp100"}
+    assert all(v[0] == 4922 for v in got.values()), got
+    assert got["cornell_spp25"][1] == 4, got
+    sat = P.saturated_mask("cornell_spp25")
+    ys, xs = np.nonzero(emit)
+    far = [(r, c) for r, c in np.argwhere(sat & ~emit) if r > ys.max() + 100]
+    assert len(far) == 4
+    # the silhouette has 2 x 211 pixels of horizontal edge: nudging the image plane by 0.05 pixel must be visible
+    rays = s.primary_rays().reshape(s.height, s.width, 6)
+    eye = rays[0, 0, :3]
+    pos = eye + rays[..., 3:] * ((s.camera[5] - eye[2]) / rays[..., 5])[..., None]       # on the plane through look_at
+    d = pos + 0.05 * (pos[1, 0] - pos[0, 0]) - eye
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    face, _, _, _ = s.trace_closest(np.ascontiguousarray(np.concatenate([np.broadcast_to(eye, d.shape), d], axis=-1)).reshape(-1, 6))
+    _, mat, _ = s.faces()
+    is_light = np.array([s.material(i)[2][3] >= 0 for i in range(s.num_materials)])
+    nudged = ((face >= 0) & is_light[mat[np.maximum(face, 0)]]).reshape(s.height, s.width)
+    assert int((sat & ~nudged).sum()) > 150
 
 
-def test_veach_matches_published_render_statistically(oracle):
-    """veach-mis exercises five lights, the frozen light-area distribution (Q1) and the Phong lobe; the published files are
-    truncated by one row (no fclose in imshow) but 899 rows decode."""
-    g = np.load(os.path.join(GOLD, "published_renders.npz"))
-    pub = g["veach_spp10"]                                                             # [56,75,3]
-    s = oracle.OracleScene(SCENES + "veach-mis", texture_dir=SCENES, width=300, height=225)
-    img = s.render(10, seed=7)
-    mine = _blocks(oracle.quantize(img)[:224], 4)
-    assert mine.shape == pub.shape
-    assert abs(mine.mean() - pub.mean()) < 0.02 * pub.mean(), (mine.mean(), pub.mean())
+def test_veach_emitter_pixels_are_saturated_in_the_published_renders(oracle):
+    """veach-mis: five sphere lights, 45 266 emitter pixels at the native 1200x900; the published files hold 899 rows (no
+    fclose in imshow).  One-sided here: a quarter of the frame is saturated by reflections of the lights."""
+    s = oracle.OracleScene(SCENES + "veach-mis", texture_dir=SCENES)
+    assert (s.width, s.height) == (1200, 900)
+    got = P.check_emitter_pixels(_emitter_map(oracle, s), "veach-mis")
+    assert got["veach_spp10"][0] == 45266 and got["veach_spp100"][0] == 45266, got
+
+
+def _oracle_blocks(oracle, s, name, spp, step, seeds):
+    out = []
+    for seed in seeds:
+        img = np.zeros((s.height, s.width, 3))
+        for br, bc in P.selected_blocks(name, step):
+            s.render(spp, seed=seed, rows=(br * P.BLOCK, (br + 1) * P.BLOCK), cols=(bc * P.BLOCK, (bc + 1) * P.BLOCK), img=img)
+        out.append(oracle.quantize(img))
+    return out
+
+
+def test_cornell_matches_published_render_at_monte_carlo_precision(oracle):
+    """The shipped main() renders cornell-box at SPP 25 (MTPC/MTPC.cpp:78); result/cornell-box-SPP25.png is that run.  Every
+    4th 16x16 block in both directions, native resolution, SPP 25, two seeds: block z-scores are standard normal (measured:
+    mean -0.02, rms 0.99, none beyond 4).  The median sigma of a block is ~1 % of its value, so the mean z over 768 values
+    resolves a 0.2 % difference in brightness; a wrong tie-break that moves a silhouette or a missing weight is far above that."""
+    s = oracle.OracleScene(SCENES + "cornell-box", texture_dir=SCENES)
+    a, b = _oracle_blocks(oracle, s, "cornell_spp25", 25, 4, (11, 12))
+    diff, sigma = P.block_stats("cornell_spp25", a, b, 4)
+    assert diff.shape == (256, 3)
+    print(P.assert_standard_normal(diff, sigma, "cornell-box SPP25"))
+
+
+def test_veach_matches_published_render_at_monte_carlo_precision(oracle):
+    """veach-mis exercises five lights, the frozen light-area distribution (Q1: without it lights 2-5 are sampled over their
+    whole area and the picture changes materially) and the Phong lobe.  SPP 10, every 5th block, native resolution."""
+    s = oracle.OracleScene(SCENES + "veach-mis", texture_dir=SCENES)
+    a, b = _oracle_blocks(oracle, s, "veach_spp10", 10, 5, (21, 22))
+    diff, sigma = P.block_stats("veach_spp10", a, b, 5)
+    print(P.assert_standard_normal(diff, sigma, "veach-mis SPP10", mean_tol=0.45, rms=(0.8, 1.45), tail=0.02, drop_saturated=True))
+
+
+def test_config1_cornell_400x400_spp2(oracle, tmp_path):
+    """BASELINE config 1: cornell-box 400x400 SPP 2 on the CPU (plumbing): the oracle renders it (reference-cost mode), writes
+    the PNG with its svpng restatement and reads it back; the work it did has the reference's composition for this framing
+    (1 + 1.92 + 1.16 rays per sample, 7.47 triangle tests per ray -- resolution-independent figures).
+    result/cornell-box-SPP2.png is the published picture of this scene at SPP 2, but of another revision of the integrator
+    (1.5 % brighter than the oracle, as SPP16/SPP50 are than SPP25, which the oracle matches to 0.03 %), and at SPP 2 the 8-bit
+    clamp removes a different share of the fireflies than at SPP 25 -- so it is held loosely: block means within 3 %."""
+    s = oracle.OracleScene(SCENES + "cornell-box", texture_dir=SCENES, width=400, height=400)
+    s.set_walk_mode(oracle.TRACE_ALIAS)
+    st = oracle.Stats()
+    img = oracle.quantize(s.render(2, seed=5, faithful_cost=True, stats=st))
+    n = float(st.samples)
+    assert st.samples == 400 * 400 * 2 == st.rays_primary
+    assert abs(st.rays_shadow / n - 1.92) < 0.03 and abs(st.rays_bounce / n - 1.16) < 0.03 and abs(st.tri_tests / st.rays - 7.47) < 0.06
+    png = oracle.png_encode(img)
+    f = tmp_path / "cornell-box-SPP2.png"
+    f.write_bytes(png)
+    w, h, rows = oracle.read_stored_png(str(f))
+    assert (w, h) == (400, 400) and np.array_equal(rows, img)
+    pub, _ = P.published_blocks("cornell_spp2_result")                        # [64, 64, 3] means of 16x16 pixels
+    pub = pub.astype(np.float64).reshape(16, 4, 16, 4, 3).mean(axis=(1, 3))   # -> 64x64-pixel blocks = 25x25 of ours
+    mine = img.astype(np.float64).reshape(16, 25, 16, 25, 3).mean(axis=(1, 3))
+    assert abs(mine.mean() / pub.mean() - 1) < 0.03, (mine.mean(), pub.mean())
     assert np.corrcoef(mine.ravel(), pub.ravel())[0, 1] > 0.98
+
+
+# SURVEY.md section 3.5: work composition of the REFERENCE ITSELF (an instrumented g++ build of the unmodified sources, measured
+# when the survey was written): rays per camera sample = 1 primary + shadow + bounce, shade calls per sample, box tests and
+# triangle tests per ray.  (scene, width, height, spp): (shadow, bounce, shade, box, tri)
+REFERENCE_COMPOSITION = {
+    ("cornell-box", 200, 200, 16): (1.92, 1.16, 1.94, 172.2, 7.47),
+    ("veach-mis", 200, 150, 16): (6.57, 0.79, 1.40, 264.2, 9.51),
+    ("cornell-box", 320, 180, 8): (1.08, 0.65, 1.09, 145.0, 6.30),
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(REFERENCE_COMPOSITION))
+def test_work_composition_equals_the_instrumented_reference(oracle, cfg):
+    """The oracle walking its rays exactly as bvh_intersect is written (virtual children aliased, Q7) over the leaf order a
+    libstdc++ std::sort leaves (oracle/std_sort_order.cpp; the reference's sort is unstable, D2) does the work the reference
+    did, figure for figure: box tests per ray agree to 4 digits on veach-mis (264.26 vs 264.2) -- a count that every box of the
+    tree, the order of the leaves, the slab test's accept/reject rule and the set of rays (hence every shading decision that
+    spawns one) enter.  With the oracle's own stable order (D2) the same scene takes 249.4: the deviation is visible, and it
+    changes the cost of the reference walk and which of two equidistant triangles is named, nothing else (checked below)."""
+    scene, w, h, spp = cfg
+    shadow, bounce, shade, box, tri = REFERENCE_COMPOSITION[cfg]
+    s = oracle.OracleScene(SCENES + scene, texture_dir=SCENES, width=w, height=h)
+    stable = s.leaf_order().copy()
+    s.set_leaf_order(oracle.ORDER_LIBSTDCXX)
+    assert sorted(s.leaf_order().tolist()) == sorted(stable.tolist()) and not np.array_equal(s.leaf_order(), stable)
+    s.set_walk_mode(oracle.TRACE_ALIAS)
+    st = oracle.Stats()
+    s.render(spp, seed=1, faithful_cost=True, stats=st)
+    n = float(st.samples)
+    assert st.rays_primary == st.samples == w * h * spp
+    got = (st.rays_shadow / n, st.rays_bounce / n, st.shade_calls / n, st.box_tests / st.rays, st.tri_tests / st.rays)
+    for name, g, want, tol in zip(("shadow rays / sample", "bounce rays / sample", "shade calls / sample", "box tests / ray", "triangle tests / ray"),
+                                  got, (shadow, bounce, shade, box, tri), (0.006, 0.015, 0.006, 0.003, 0.005)):
+        assert abs(g - want) <= tol * want + 0.5 * 10 ** -(2 if want < 100 else 1), (name, g, want)
+    if scene == "veach-mis":                      # what D2 changes: the stable order is a tighter tree for the same walk
+        s.set_leaf_order(oracle.ORDER_STABLE)
+        assert np.array_equal(s.leaf_order(), stable)
+        st2 = oracle.Stats()
+        s.render(spp, seed=1, faithful_cost=True, stats=st2)
+        assert (st2.rays_shadow, st2.rays_bounce, st2.shade_calls) == (st.rays_shadow, st.rays_bounce, st.shade_calls)
+        assert 0.93 < (st2.box_tests / st2.rays) / box < 0.955
+        from conftest import make_rays
+        rays = make_rays(s, 20000, seed=5)
+        f0, t0, p0, _ = s.trace_closest(rays)
+        s.set_leaf_order(oracle.ORDER_LIBSTDCXX)
+        f1, t1, p1, _ = s.trace_closest(rays)
+        assert np.array_equal(f0 >= 0, f1 >= 0)
+        hit = f0 >= 0
+        assert np.array_equal(t0[hit].view(np.uint64), t1[hit].view(np.uint64)) and (f0 != f1).mean() < 2e-3
