@@ -691,6 +691,7 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
                      (c.pad[0] + c.pad[2]) ? double(c.pad[4]) / (c.pad[0] + c.pad[2]) : 0.0,
                      tot ? 100.0 * c.pad[5] / tot : 0.0, tot ? 100.0 * c.pad[6] / tot : 0.0, tot ? 100.0 * c.pad[7] / tot : 0.0,
                      c.pad[0] ? double(c.pad[6]) / c.pad[0] : 0.0, c.pad[2] ? double(c.pad[7]) / c.pad[2] : 0.0);
+        std::fprintf(stderr, "rays deferred to the exact walk by k_wf_trace: %llu of %llu\n", c.pad[12], c.trace_rays);
         const double lt = double(c.pad[8] + c.pad[9] + c.pad[10]);
         std::fprintf(stderr, "logic diag: resolve %.1f%% compaction %.1f%% shade %.1f%% | cycles per wave: %.0f / %.0f / %.0f (waves %llu)\n",
                      lt ? 100.0 * c.pad[8] / lt : 0.0, lt ? 100.0 * c.pad[9] / lt : 0.0, lt ? 100.0 * c.pad[10] / lt : 0.0,

@@ -110,7 +110,7 @@ struct DCounters {
     unsigned long long rays_primary, rays_shadow, rays_bounce, node_visits, tri_tests, shade_calls, samples, max_depth;
     unsigned long long shadow_skipped;   // shadow rays the reference traces although their result is never used (light behind the surface)
     unsigned long long trace_rays, trace_nodes, trace_tris;   // work done inside the dominant kernel (k_wf_trace) only
-    unsigned long long pad[12];   // diagnostics (MCPT_TRACE_DIAG builds)
+    unsigned long long pad[16];   // diagnostics (MCPT_TRACE_DIAG builds; [12] = rays k_wf_trace handed to the exact walk)
 };
 
 }  // namespace mcpt

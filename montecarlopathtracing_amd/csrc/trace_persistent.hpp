@@ -38,6 +38,20 @@ namespace mcpt {
 #ifndef MCPT_INNER_BURST
 #define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
 #endif
+#ifndef MCPT_POP_CULL
+#define MCPT_POP_CULL 0             /* 1: every stack entry carries a lower bound of its entry distance (16 bits: the upper half of the
+                                       fp32 bound, i.e. rounded down); an entry popped after the ray's limit has moved in front of it is
+                                       dropped instead of visited */
+#endif
+#ifndef MCPT_INBAND_INPLACE
+#define MCPT_INBAND_INPLACE 1       /* 0: a ray with two candidates the products cannot rank goes to the exact walk instead */
+#endif
+#ifndef MCPT_LAZY_VERIFY
+#define MCPT_LAZY_VERIFY 1          /* 1: a triangle whose test passes only has the RANK of its distance looked at (two multiplies);
+                                       the own-box test and the division of t_k are done once per ray, for the winner, when the
+                                       results of a batch of finished rays are stored (>= MCPT_REFILL_LANES lanes at once).  Done per
+                                       passing triangle they ran for ~7 lanes of 64 and were a third of the kernel's instructions. */
+#endif
 
 // Src must provide:  long long total() const;
 //                    bool fetch(long long q, Ray& r) const;        // false: slot holds no ray (loads may be speculative)
@@ -53,7 +67,8 @@ namespace mcpt {
 template <class Src>
 __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src, TraceQueue* queue, long long* __restrict__ slow_list,
                                                  unsigned int slow_cap, long long chunk, int* __restrict__ stack, int stride,
-                                                 double* __restrict__ raybuf /* this wave's MCPT_RAYBUF_BYTES of LDS */, Work& w)
+                                                 double* __restrict__ raybuf /* this wave's MCPT_RAYBUF_BYTES of LDS */, Work& w,
+                                                 unsigned short* __restrict__ kstack = nullptr /* MCPT_POP_CULL: [depth][lane] like stack */)
 {
     const DFast& F = S.fast;
     const CwNode* __restrict__ nodes = F.cw;
@@ -85,7 +100,35 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     double margin = 0, limit = 0;
     bool found = false;
     Hit best; best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
+#if MCPT_LAZY_VERIFY
+    // best.t holds the product (p.x - o.x) * (1 / d.x) of the leading candidate (within 2^-50 of its t_k), best.leaf its slot in
+    // the fast triangle array; the candidate is verified (own box) and t_k divided out in finish_ray().
+    bool ambiguous = false;             // two candidates closer than the products can tell apart: the ray goes to the exact walk
+#endif
     int sp = 0, cur = 0, tri_i = 0, tri_end = 0;
+
+    // A finished ray's result goes to memory (called for a batch of idle lanes at a time).
+    auto finish_ray = [&]() {
+#if MCPT_LAZY_VERIFY
+        // The leading candidate was chosen by rank alone.  It is the reference's answer iff its own box passes the reference's
+        // slab test (a candidate that fails it must not have displaced anything) and no other candidate came within the
+        // resolution of the products; otherwise the ray is re-walked exactly (reference-shaped walk, second launch).
+        Hit h; h.leaf = -1; h.t = 0; h.p = best.p;
+        if (found) {
+            const DTri* tr = tris + best.leaf;
+            if (!own_box_hit(tr, r, rcp)) ambiguous = true;
+            h.leaf = tr->leaf;
+            h.t = (best.p.x - r.o.x) / r.d.x;                   // pathTracing.cpp:347
+        }
+        if (ambiguous) {
+            const unsigned int at = atomicAdd(&queue->slow_count, 1u);
+            if (at < slow_cap) slow_list[at] = slot;
+            else queue->redo_all = 1u;                          // list full: the second pass re-walks every slot
+        } else src.store(slot, found, h);
+#else
+        src.store(slot, found, best);
+#endif
+    };
 
     // claim the next <= 64 slots and issue their loads (stage 1)
     auto request = [&]() {
@@ -124,7 +167,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         if (idle && supply && (__popcll(idle) >= MCPT_REFILL_LANES || idle == ~0ull)) {
             // results of the rays that ended since the last refill go out in one batch: a store between two node loads
             // would put its acknowledge time on the walking lanes' critical path (loads and stores share one counter)
-            if (state == ST_IDLE && slot >= 0) { src.store(slot, found, best); slot = -1; }
+            if (state == ST_IDLE && slot >= 0) { finish_ray(); slot = -1; }
             for (;;) {
                 idle = __ballot(state == ST_IDLE);
                 if (!idle) break;
@@ -157,6 +200,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                             limit = __builtin_inf(); limit_f = __builtin_inff();
                             rf = make_rayf(F, r, rcp);
                             found = false; best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
+#if MCPT_LAZY_VERIFY
+                            ambiguous = false;
+#endif
                             sp = 0; cur = 0; state = ST_INNER;
                         } else {
                             const unsigned int at = atomicAdd(&queue->slow_count, 1u);
@@ -188,17 +234,39 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
 #pragma unroll 1
             for (int burst = 0; burst < MCPT_INNER_BURST; burst++)
             if (state == ST_INNER) {
+#if MCPT_LAZY_VERIFY
+                // three pushes must fit: a ray whose stack would overflow (deeper than this build's MCPT_FAST_STACK) goes to the exact walk
+                if (sp > MCPT_FAST_STACK - 3) { ambiguous = true; state = ST_IDLE; }
+                else {
+#else
+                {
+#endif
                 w.nodes++;
                 const CwHits h = cw_step(nodes + cur, rf, limit_f);
                 // nearest first; the others go on the stack so that the next nearest is on top
+#if MCPT_POP_CULL
+#define MCPT_KEY16(x) ((unsigned short)(__float_as_uint(fmaxf((x), 0.0f)) >> 16))
+                if (h.ref[3] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[3]; kstack[sp * stride] = MCPT_KEY16(h.key[3]); sp++; }
+                if (h.ref[2] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[2]; kstack[sp * stride] = MCPT_KEY16(h.key[2]); sp++; }
+                if (h.ref[1] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[1]; kstack[sp * stride] = MCPT_KEY16(h.key[1]); sp++; }
+                int nxt = h.ref[0];
+                if (nxt == MCPT_FAST_EMPTY) {
+                    while (sp > 0) {
+                        sp--;
+                        if (__uint_as_float((unsigned)kstack[sp * stride] << 16) <= limit_f) { nxt = stack[sp * stride]; break; }
+                    }
+                }
+#else
                 if (h.ref[3] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[3]; sp++; }
                 if (h.ref[2] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[2]; sp++; }
                 if (h.ref[1] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[1]; sp++; }
                 int nxt = h.ref[0];
                 if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = stack[sp * stride]; }
+#endif
                 if (nxt >= 0) cur = nxt;
                 else if (nxt == MCPT_FAST_EMPTY) state = ST_IDLE;                 // result stored at the next refill
                 else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; state = ST_TRI; }
+                }
             }
         } else {
             // -------------------------------------------------------------- one triangle of the current leaf
@@ -211,25 +279,64 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                 V3 p;
                 w.tris++;
                 if (tri_hit(tr, r, p)) {
+#if MCPT_LAZY_VERIFY
+                    // t_k = (p.x - o.x) / d.x is within 2^-50 (relative) of this product and has its sign: two candidates whose
+                    // products differ by more than 2^-47 are ranked like their t_k
+                    const double ta = (p.x - r.o.x) * rcp.x;
+                    if (ta > 0.0) {
+                        const double band = best.t * 0x1p-47;
+                        if (!found || ta < best.t - band) {
+                            found = true; best.leaf = tri_i - 1; best.t = ta; best.p = p;
+                            limit = (ta + ta * 0x1p-47) + margin;
+                            limit_f = __double2float_ru(limit);
+                        } else if (!(ta > best.t + band)) {
+                            // closer to the leader than the products resolve (a shared edge, a face listed twice, two sides of
+                            // a sheet): rank the two by the reference's own t_k and leaf index, provided this one is a candidate
+                            // at all.  The leader's own box is looked at when the ray is finished, like any leader's.
+#if !MCPT_INBAND_INPLACE
+                            ambiguous = true;
+#else
+                            if (own_box_hit(tr, r, rcp)) {
+                                const double t_new = (p.x - r.o.x) / r.d.x, t_old = (best.p.x - r.o.x) / r.d.x;
+                                if (t_new < t_old || (t_new == t_old && tr->leaf < tris[best.leaf].leaf)) {
+                                    best.leaf = tri_i - 1; best.t = ta; best.p = p;
+                                }
+                            }
+#endif
+                        }
+                    }
+#else
                     double t; int k;
                     if (better_candidate(tr, r, rcp, p, found, best, t, k)) {
                         found = true; best.leaf = k; best.t = t; best.p = p;
                         limit = t + margin;
                         limit_f = __double2float_ru(limit);
                     }
+#endif
                 }
                 if (tri_i >= tri_end) {                  // leaf done: pop
+#if MCPT_POP_CULL
+                    int nxt = MCPT_FAST_EMPTY;
+                    while (sp > 0) {
+                        sp--;
+                        if (__uint_as_float((unsigned)kstack[sp * stride] << 16) <= limit_f) { nxt = stack[sp * stride]; break; }
+                    }
+                    if (nxt >= 0) { cur = nxt; state = ST_INNER; }
+                    else if (nxt == MCPT_FAST_EMPTY) state = ST_IDLE;
+                    else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
+#else
                     if (sp > 0) {
                         sp--;
                         const int nxt = stack[sp * stride];
                         if (nxt >= 0) { cur = nxt; state = ST_INNER; }
                         else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
                     } else state = ST_IDLE;
+#endif
                 }
             }
         }
     }
-    if (slot >= 0) src.store(slot, found, best);
+    if (slot >= 0) finish_ray();
 }
 
 // second pass: the deferred rays, one lane each, reference-shaped walk.  If more rays were deferred than the side list
@@ -252,9 +359,10 @@ __device__ __forceinline__ void trace_slow_list(const DScene& S, const Src& src,
         }
     } else {
         const long long total = src.total();
+        const bool redo_all = queue->redo_all != 0;        // a ray the fast walk could not decide did not fit into the list
         for (long long q = first; q < total; q += stride) {
             Ray r;
-            if (!src.fetch(q, r) || fast_path_ok(S.fast, r)) continue;
+            if (!src.fetch(q, r) || (!redo_all && fast_path_ok(S.fast, r))) continue;
             Hit h;
             const bool ok = trace_closest(S, r, h, w);
             src.store(q, ok, h);

@@ -263,10 +263,16 @@ __global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, Wf
     const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk, max_chunk);
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
+#if MCPT_POP_CULL
+    __shared__ unsigned short lds_keys[MCPT_FAST_STACK * 256];
+    unsigned short* keys = lds_keys + threadIdx.x;
+#else
+    unsigned short* keys = nullptr;
+#endif
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys);
     ls.nodes = w.nodes; ls.tris = w.tris;
     if (a.ctr) {        // the dominant kernel's own work, for its roofline
         const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays);
@@ -282,6 +288,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_slow(DScene S, WfArgs a, const
 {
     const long long n_paths = a.counts->n_next;
     if (n_paths <= (long long)a.finish_below || queue->slow_count == 0) return;
+    if (a.ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.ctr->pad[12], (unsigned long long)queue->slow_count);   // diagnostics
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};

@@ -51,7 +51,8 @@ struct alignas(16) PrimarySurface {
 struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
     unsigned long long head;        // next ticket (trace_persistent.hpp maps tickets to ray slots)
     unsigned int slow_count;        // rays deferred to the reference-shaped walk (may exceed the list capacity)
-    unsigned int pad[13];
+    unsigned int redo_all;          // set when a ray the fast walk could not decide found the list full
+    unsigned int pad[12];
 };
 
 struct WfCounts {           // one per iteration, on the device: slot 0 = hit pixels of the chunk, slot d+1 = paths alive after

@@ -235,11 +235,12 @@ def test_wavefront_iterations_against_megakernel_and_oracle(pair, oracle, mcpt, 
 
 def _gpu_emitter_map(mcpt, sc, dev):
     """[H, W] bool from the product's own frame: at SPP 1 a pixel whose primary hit is an emitter holds the light's radiance
-    exactly (pathTracing.cpp:141-144; k_primary_dirs -> primary hits -> k_wf_logic<true>), nothing else does."""
+    exactly -- rounded to float, the accumulator is a glm::vec3 (pathTracing.cpp:141-144, :301; k_primary_dirs -> primary hits
+    -> k_wf_logic<true> -> k_fold_samples) -- and nothing else does."""
     img = dev.generateImg(1, seed=1)
     emit = np.zeros(img.shape[:2], dtype=bool)
     for l in range(sc.info.num_lights):
-        emit |= (img == sc.light(l)[1][None, None, :]).all(axis=2)
+        emit |= (img == sc.light(l)[1].astype(np.float32).astype(np.float64)[None, None, :]).all(axis=2)
     return emit
 
 
