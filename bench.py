@@ -185,7 +185,7 @@ def main():
         class _Sim:
             def __init__(self):
                 import torch as _t
-                self.frame = _t.zeros((scene.info.height * scene.info.width, 3), dtype=_t.float64, device=tdev)
+                self.frame = _t.zeros((dev.height * dev.width, 3), dtype=_t.float64, device=tdev)
             def render(self, spp, seed=0, stats=None, flags=0):
                 dev.render_device(self.frame.data_ptr(), spp, seed, args.sim_rank, args.sim_world, 0, 0, flags, stats,
                                   torch.cuda.current_stream(tdev).cuda_stream)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCPT_VERSION 101
+#define MCPT_VERSION 102
 
 #define MCPT_OK             0
 #define MCPT_ERR_IO        -1   /* a scene/texture/output file could not be opened */
@@ -184,6 +184,25 @@ int  mcpt_sample_radiance(mcpt_device*, uint64_t seed, const int32_t* pix, const
 /* number of pixels owned by (rank, world) under the tile partition, and their indices (row*W+col, ascending) */
 int64_t mcpt_owned_pixels(const mcpt_scene*, const mcpt_render_params*, int32_t* pixels /* may be NULL */);
 
+/* ---- integrator over several GPUs of one node (no reference counterpart: generateImg is single-process OpenMP) ---- */
+/* The frame is cut into tiles dealt to the GPUs exactly as mcpt_render_params.rank/world describe (rank r = devices[r]); the scene
+ * is resident on every GPU; one host thread per GPU renders its tiles; at the end of the frame every rank's pixels travel as one
+ * compact buffer into devices[0]'s HBM and are put at their frame positions there.  Every (pixel, sample) owns its RNG key, so the
+ * frame is bit-identical for any number of GPUs (and to mcpt_render).  An ordinal may appear more than once in devices[] (several
+ * ranks sharing a GPU: how the exchange is tested on a one-GPU box; MCPT_GATHER_PEER only). */
+typedef struct mcpt_multi mcpt_multi;
+#define MCPT_GATHER_PEER 0   /* hipMemcpyPeerAsync into devices[0] (over xGMI between the GPUs of a node) */
+#define MCPT_GATHER_RCCL 1   /* ncclSend / ncclRecv in one group (librccl.so is loaded at mcpt_multi_create); distinct ordinals only */
+/* devices == NULL or num_devices <= 0: every visible GPU.  build_mode as mcpt_device_create_ex (MCPT_BUILD_HOST needs a host build). */
+int  mcpt_multi_create(const mcpt_scene*, const int32_t* devices, int32_t num_devices, int32_t build_mode, int32_t gather, mcpt_multi** out);
+int  mcpt_multi_num_devices(const mcpt_multi*);
+/* generateImg on all the GPUs: img = H*W*3 doubles on the host (every pixel is written); params->rank/world are ignored.
+ * stats (may be NULL): counts summed over the GPUs, ms_total = slowest GPU + exchange, ms_trace = slowest GPU's. */
+int  mcpt_multi_render(mcpt_multi*, const mcpt_render_params*, double* img, mcpt_stats* stats);
+/* the same, leaving the frame in devices[0]'s HBM: *d_img (owned by the handle, valid until the next call) */
+int  mcpt_multi_render_device(mcpt_multi*, const mcpt_render_params*, double** d_img, mcpt_stats* stats);
+void mcpt_multi_free(mcpt_multi*);
+
 /* ---- output (imshow + svpng) ---- */
 int  mcpt_quantize_rgb8(const double* img, int64_t n, uint8_t* rgb8);        /* (unsigned char)clamp(v*255,0,255) */
 int  mcpt_write_png(const char* file, const uint8_t* rgb8, int32_t width, int32_t height);
@@ -205,7 +224,7 @@ int  mcpt_checkpoint_load(const char* file, const mcpt_scene* scene, double* img
 int  mcpt_decode_jpeg(const char* file, int32_t* width, int32_t* height, uint8_t* bgr, int64_t cap);
 
 /* ---- whole program (render_scene) ---- */
-/* Reads <path><filename>.*, renders with N samples per pixel on GPU 0 and writes
+/* Reads <path><filename>.*, renders with N samples per pixel on GPU 0 (or the GPUs named by the options) and writes
  * "../result/<filename>-SPP<N>.png" relative to the cwd, like the reference. */
 int  mcpt_render_scene(const char* path, const char* filename, int32_t spp);
 #define MCPT_OUT_PNG_DEFLATE  1      /* the .png is deflate-compressed (same pixels; the reference's svpng stores them raw) */
@@ -223,6 +242,10 @@ typedef struct {
                                    after each, and a run that finds a matching file resumes after the partitions it holds */
     int32_t  checkpoint_parts;  /* 0 -> 8 */
     int32_t  reserved;
+    /* since MCPT_VERSION 102: the frame on several GPUs of the node (mcpt_multi_*); all zero = one GPU (`device`) */
+    int32_t  num_devices;       /* > 0: devices[0..num_devices); -1: every visible GPU */
+    int32_t  gather;            /* MCPT_GATHER_* */
+    const int32_t* devices;     /* NULL with num_devices > 0: ordinals 0..num_devices-1 */
 } mcpt_render_scene_options;
 int  mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options*, mcpt_stats* stats);
 

@@ -60,7 +60,8 @@ class RenderSceneOptions(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("quiet", C.c_int32), ("output_prefix", C.c_char_p),
                 ("load_flags", C.c_int32), ("output_flags", C.c_int32), ("checkpoint", C.c_char_p),
-                ("checkpoint_parts", C.c_int32), ("reserved", C.c_int32)]
+                ("checkpoint_parts", C.c_int32), ("reserved", C.c_int32),
+                ("num_devices", C.c_int32), ("gather", C.c_int32), ("devices", C.POINTER(C.c_int32))]
 
 
 # every symbol include/mcpt.h declares
@@ -75,6 +76,7 @@ EXPORTS = [
     "mcpt_render", "mcpt_render_device", "mcpt_sample_radiance", "mcpt_owned_pixels",
     "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_png_encode_deflate", "mcpt_write_png_deflate", "mcpt_write_pfm",
     "mcpt_checkpoint_save", "mcpt_checkpoint_load", "mcpt_decode_jpeg",
+    "mcpt_multi_create", "mcpt_multi_num_devices", "mcpt_multi_render", "mcpt_multi_render_device", "mcpt_multi_free",
     "mcpt_render_scene", "mcpt_render_scene_ex",
 ]
 
@@ -141,6 +143,12 @@ def lib():
     L.mcpt_checkpoint_save.argtypes = [C.c_char_p, P, D, C.c_int32, C.c_uint64, C.c_int32, U8]
     L.mcpt_checkpoint_load.argtypes = [C.c_char_p, P, D, C.c_int32, C.c_uint64, C.c_int32, U8]
     L.mcpt_decode_jpeg.argtypes = [C.c_char_p, I32, I32, U8, C.c_int64]
+    L.mcpt_multi_create.argtypes = [P, I32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(P)]
+    L.mcpt_multi_num_devices.argtypes = [P]
+    L.mcpt_multi_render.argtypes = [P, C.POINTER(RenderParams), D, C.POINTER(Stats)]
+    L.mcpt_multi_render_device.argtypes = [P, C.POINTER(RenderParams), C.POINTER(P), C.POINTER(Stats)]
+    L.mcpt_multi_free.argtypes = [P]
+    L.mcpt_multi_free.restype = None
     L.mcpt_render_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     L.mcpt_render_scene_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(RenderSceneOptions), C.POINTER(Stats)]
     _lib = L

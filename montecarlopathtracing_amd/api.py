@@ -14,6 +14,7 @@ LOAD_STANDARD_OBJ, LOAD_MTLLIB, LOAD_MORTON_BOUNDS = 1, 2, 4
 OUT_PNG_DEFLATE, OUT_PFM = 1, 2
 BUILD_HOST, BUILD_DEVICE, BUILD_DEVICE_FAST = 0, 1, 2
 SCENE_DEFER_BUILD = 1
+GATHER_PEER, GATHER_RCCL = 0, 1
 
 
 def _p(a, t):
@@ -229,6 +230,44 @@ class Device:
         return rgb
 
 
+class MultiDevice:
+    """generateImg on several GPUs of the node behind one call (mcpt_multi_*): one host thread per GPU inside the library, tiles
+    dealt like rank/world, every rank's pixels gathered into devices[0]'s HBM (peer copies over xGMI, or RCCL)."""
+
+    def __init__(self, scene, devices=None, build=BUILD_HOST, gather=GATHER_PEER):
+        self.scene = scene
+        self._h = C.c_void_p()
+        if devices is None:
+            arr, n = None, 0
+        else:
+            devices = np.ascontiguousarray(devices, dtype=np.int32)
+            arr, n = _p(devices, C.c_int32), devices.shape[0]
+        check(lib().mcpt_multi_create(scene._h, arr, n, build, gather, C.byref(self._h)))
+        i = scene.info
+        self.width, self.height = i.width, i.height
+
+    @property
+    def num_devices(self):
+        return lib().mcpt_multi_num_devices(self._h)
+
+    def generateImg(self, spp, seed=0, tile_w=0, tile_h=0, flags=0, stats=None):
+        img = np.zeros((self.height, self.width, 3))
+        rp = RenderParams(spp, seed, 0, 1, tile_w, tile_h, flags)
+        check(lib().mcpt_multi_render(self._h, C.byref(rp), _p(img, C.c_double), C.byref(stats) if stats is not None else None))
+        return img
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mcpt_multi_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def imshow_rgb8(img):
     """The 8-bit conversion of imshow (MTPC/MTPC.cpp:22-30)."""
     img = np.ascontiguousarray(img, dtype=np.float64)
@@ -303,10 +342,18 @@ def morton_code(x, y, z):
 
 
 def render_scene(path, filename, N_ray_per_pixel, seed=0, device=0, width=0, height=0, quiet=True, output_prefix=None, stats=None,
-                 load_flags=0, output_flags=0, checkpoint=None, checkpoint_parts=0):
-    """render_scene(path, filename, N) of MTPC/MTPC.cpp:35; writes <prefix>-SPP<N>.png (default ../result/<filename>)."""
+                 load_flags=0, output_flags=0, checkpoint=None, checkpoint_parts=0, devices=None, gather=GATHER_PEER):
+    """render_scene(path, filename, N) of MTPC/MTPC.cpp:35; writes <prefix>-SPP<N>.png (default ../result/<filename>).
+    devices: list of GPU ordinals, or -1 for every visible GPU (the frame is then rendered by mcpt_multi_*)."""
+    dev_arr, ndev = None, 0
+    if devices == -1:
+        ndev = -1
+    elif devices is not None:
+        keep = np.ascontiguousarray(devices, dtype=np.int32)
+        dev_arr, ndev = _p(keep, C.c_int32), keep.shape[0]
     o = RenderSceneOptions(seed, device, width, height, int(quiet), output_prefix.encode() if output_prefix else None,
-                           load_flags, output_flags, checkpoint.encode() if checkpoint else None, checkpoint_parts, 0)
+                           load_flags, output_flags, checkpoint.encode() if checkpoint else None, checkpoint_parts, 0,
+                           ndev, gather, dev_arr)
     check(lib().mcpt_render_scene_ex(path.encode(), filename.encode(), N_ray_per_pixel, C.byref(o),
                                      C.byref(stats) if stats is not None else None))
     return True

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <functional>
 #include <chrono>
 #include <cmath>
@@ -11,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,9 +58,30 @@ int grow(T** ptr, int64_t* cap, int64_t need)
 
 }  // namespace
 
+// the calling thread's error message, for the other translation units of the library (multi_device.cpp)
+namespace mcpt { int set_error(int code, const std::string& msg) { return fail(code, msg); } }
+
 struct mcpt_scene {
     Scene s;
+    // The fast walk's culling hierarchy depends on the scene and the leaf order only: built once, shared by every device
+    // created from this scene (one SAH build for the 8 GPUs of a node, not 8).
+    mutable std::atomic<int> devices_created{0};      // mcpt_scene_set_resolution is refused once a device holds the camera
+    mutable std::mutex fast_mu;
+    mutable std::shared_ptr<const FastBvh> fast_cached;
+    mutable std::vector<int32_t> fast_order;
 };
+
+static std::shared_ptr<const FastBvh> shared_fast_bvh(const mcpt_scene* h, const std::vector<int32_t>& order)
+{
+    std::lock_guard<std::mutex> lock(h->fast_mu);
+    if (!h->fast_cached || h->fast_order != order) {
+        auto fb = std::make_shared<FastBvh>();
+        build_fast_bvh(h->s.faces, order.data(), int(h->s.faces.size()), *fb);
+        h->fast_cached = fb;
+        h->fast_order = order;
+    }
+    return h->fast_cached;
+}
 
 struct mcpt_device {
     int ordinal = 0;
@@ -93,6 +116,7 @@ struct mcpt_device {
     TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
     long long* slow_list = nullptr;
     unsigned int slow_cap = 1u << 20;
+    LaunchCfg cfg;                                  // this GPU's resident grids and knobs
     long long finish_threshold = 500000;            // paths left at which the finishing pass takes over (MCPT_FINISH_PATHS; sweep: flat from 2e5 to 1e6)
 };
 
@@ -185,6 +209,10 @@ int mcpt_scene_create(const mcpt_scene_desc* dsc, int32_t flags, mcpt_scene** ou
 int mcpt_scene_set_resolution(mcpt_scene* s, int32_t w, int32_t h)
 {
     if (!s || w <= 0 || h <= 0) return fail(MCPT_ERR_ARG, "bad resolution");
+    // a device caches the camera frame, the primary directions and its frame size when it is created; changing the resolution
+    // under it would make callers size their frame buffers for another picture than the device writes
+    if (s->devices_created.load() > 0 && (w != s->s.width || h != s->s.height))
+        return fail(MCPT_ERR_ARG, "the resolution cannot change after a device has been created from the scene");
     s->s.width = w; s->s.height = h;
     return MCPT_OK;
 }
@@ -536,8 +564,11 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
 
     // result-identical fast structure: SAH hierarchy built on the host from the leaf order (accel_build.cpp), permuted triangle
     // copy gathered on the GPU -- or, MCPT_BUILD_DEVICE_FAST, a 4-wide tree over the Morton order built on the GPU in place
-    FastBvh fb;
-    if (!fast_on_device) build_fast_bvh(s.faces, order.data(), t, fb);
+    std::shared_ptr<const FastBvh> fb_host;
+    if (!fast_on_device) fb_host = shared_fast_bvh(h, order);
+    FastBvh fb_dev;                              // MCPT_BUILD_DEVICE_FAST: shape figures of the hierarchy built on this GPU
+    const FastBvh& fb_ro = fast_on_device ? fb_dev : *fb_host;
+    FastBvh& fb = fb_dev;
     bool coords_ok = true;                       // every coordinate zero or within [1e-150, 1e150]
     for (const FaceRec& f : s.faces)
         for (int c = 0; c < 3; c++)
@@ -589,9 +620,9 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         }
     } else {
         int32_t* d_slots = nullptr;
-        if ((rc = upload(fb.cw, &d->cw_nodes)) || (rc = upload(fb.leaf_tris, &d_slots))) { (void)hipFree(d_slots); return rc; }
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d->fast_tris), std::max<size_t>(fb.leaf_tris.size(), 1) * sizeof(DTri));
-        if (e == hipSuccess) e = device_gather_tris(d->tris, d_slots, int(fb.leaf_tris.size()), d->fast_tris, d->stream);
+        if ((rc = upload(fb_ro.cw, &d->cw_nodes)) || (rc = upload(fb_ro.leaf_tris, &d_slots))) { (void)hipFree(d_slots); return rc; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d->fast_tris), std::max<size_t>(fb_ro.leaf_tris.size(), 1) * sizeof(DTri));
+        if (e == hipSuccess) e = device_gather_tris(d->tris, d_slots, int(fb_ro.leaf_tris.size()), d->fast_tris, d->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         (void)hipFree(d_slots);
         if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("fast triangle gather: ") + hipGetErrorString(e));
@@ -603,6 +634,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->slow_list), size_t(d->slow_cap) * sizeof(long long)));
     if (const char* e = std::getenv("MCPT_FINISH_PATHS")) d->finish_threshold = std::atoll(e);
+    init_launch_cfg(d->cfg);
     if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
         const double v = std::atof(gb);
         if (v > 0.01) d->wf_budget_bytes = size_t(v * double(size_t(1) << 30));
@@ -614,9 +646,9 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     S.t = t; S.Lv = bi.Lv; S.Level = bi.Level; S.Nr = bi.Nr;
     S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
     S.area0 = s.area0;
-    S.fast.cw = d->cw_nodes; S.fast.nodes = nullptr; S.fast.tris = d->fast_tris; S.fast.absmax = fb.scene_absmax;
-    S.fast.enabled = (coords_ok && fb.max_depth < kFastMaxDepth && fb.cw_stack_need < kFastMaxDepth && fb.scene_absmax >= 1e-15 &&
-                      fb.scene_absmax <= 1e15) ? 1 : 0;
+    S.fast.cw = d->cw_nodes; S.fast.nodes = nullptr; S.fast.tris = d->fast_tris; S.fast.absmax = fb_ro.scene_absmax;
+    S.fast.enabled = (coords_ok && fb_ro.max_depth < kFastMaxDepth && fb_ro.cw_stack_need < kFastMaxDepth && fb_ro.scene_absmax >= 1e-15 &&
+                      fb_ro.scene_absmax <= 1e15) ? 1 : 0;
     const CameraFrame cf = camera_frame(s);
     S.cam.eye[0] = cf.eye.x; S.cam.eye[1] = cf.eye.y; S.cam.eye[2] = cf.eye.z;
     S.cam.start_point[0] = cf.start_point.x; S.cam.start_point[1] = cf.start_point.y; S.cam.start_point[2] = cf.start_point.z;
@@ -625,6 +657,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     S.cam.width = s.width; S.cam.height = s.height;
     d->width = s.width; d->height = s.height;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->dirs), size_t(s.width) * s.height * 3 * sizeof(double)));
+    h->devices_created.fetch_add(1);
     *out = d.release();
     return MCPT_OK;
 }
@@ -707,7 +740,7 @@ int mcpt_trace_closest_device(mcpt_device* d, const double* d_rays, int64_t n, i
     HIP_TRY(hipSetDevice(d->ordinal));
     if (!d_face || !d_t || !d_p) return fail(MCPT_ERR_ARG, "d_face, d_t and d_p are required by the device form");
     launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->queue, d->slow_list, d->slow_cap,
-                         static_cast<hipStream_t>(stream));
+                         static_cast<hipStream_t>(stream), d->cfg);
     HIP_TRY(hipGetLastError());
     return MCPT_OK;
 }
@@ -730,7 +763,7 @@ int mcpt_trace_closest(mcpt_device* d, const double* rays, int64_t n, int32_t* f
     TRY_OR_CLEAN(hipMemcpyAsync(d_rays, rays, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice, d->stream));
     TRY_OR_CLEAN(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), d->stream));
     TRY_OR_CLEAN(hipEventRecord(d->ev[0], d->stream));
-    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->queue, d->slow_list, d->slow_cap, d->stream);
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->queue, d->slow_list, d->slow_cap, d->stream, d->cfg);
     TRY_OR_CLEAN(hipGetLastError());
     TRY_OR_CLEAN(hipEventRecord(d->ev[1], d->stream));
     if (face) TRY_OR_CLEAN(hipMemcpyAsync(face, d_face, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
@@ -889,16 +922,16 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
             a.counts_in = &d->wf_counts[depth]; a.count_mul = depth == 0 ? unsigned(spp) : 1u;
             a.counts = &d->wf_counts[depth + 1];
             const long long n_launch = std::max<long long>(1, (long long)n_grid);
-            launch_wf_logic(d->ds, a, n_launch, depth == 0, st);
+            launch_wf_logic(d->ds, a, n_launch, depth == 0, st, d->cfg);
             HIP_TRY(hipGetLastError());
             if (a.finish_below) {
                 // few paths left (decided on the device from this pass's count): one lane per path runs them to the end
-                launch_wf_finish(d->ds, a, std::min<long long>(n_launch, (long long)a.finish_below), st);
+                launch_wf_finish(d->ds, a, std::min<long long>(n_launch, (long long)a.finish_below), st, d->cfg);
                 HIP_TRY(hipGetLastError());
             }
             std::pair<hipEvent_t, hipEvent_t>* pr = nullptr;
             if (stats) { if ((rc = next_pair(pr))) return rc; HIP_TRY(hipEventRecord(pr->first, st)); }
-            launch_wf_trace(d->ds, a, n_launch, fast, d->queue, d->slow_list, d->slow_cap, st);
+            launch_wf_trace(d->ds, a, n_launch, fast, d->queue, d->slow_list, d->slow_cap, st, d->cfg);
             HIP_TRY(hipGetLastError());
             if (stats) HIP_TRY(hipEventRecord(pr->second, st));
             launches++;
@@ -915,7 +948,7 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
         if (n_upper > 0) {
             a.depth = MCPT_MAX_DEPTH;
             a.counts_in = &d->wf_counts[MCPT_MAX_DEPTH]; a.count_mul = 1u; a.counts = &d->wf_counts[MCPT_MAX_DEPTH + 1];
-            launch_wf_logic(d->ds, a, n_upper, false, st);
+            launch_wf_logic(d->ds, a, n_upper, false, st, d->cfg);
             HIP_TRY(hipGetLastError());
         }
         launch_fold_samples(d->rad, d->pixels, d->hits, int(first), n_slots, spp, d_img, st);
@@ -947,7 +980,7 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
     if ((rc = grow(&d->hits, &d->hits_cap, npx))) return rc;
     HIP_TRY(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), st));
     HIP_TRY(hipEventRecord(d->ev[0], st));
-    launch_primary_hits(d->ds, d->trace_mode == MCPT_TRACE_FAST, d->dirs, d->pixels, int(npx), d->hits, d->ctr, d->queue, d->slow_list, d->slow_cap, st);
+    launch_primary_hits(d->ds, d->trace_mode == MCPT_TRACE_FAST, d->dirs, d->pixels, int(npx), d->hits, d->ctr, d->queue, d->slow_list, d->slow_cap, st, d->cfg);
     HIP_TRY(hipGetLastError());
     double ms_trace = 0;
     int launches = 0;
@@ -1079,9 +1112,30 @@ int mcpt_write_pfm(const char* file, const double* img, int32_t w, int32_t h)
     return rc ? fail(rc, err) : MCPT_OK;
 }
 
+// Identity of the frame a checkpoint belongs to: FNV-1a over everything the picture depends on besides spp / seed / parts
+// (which the file header carries): geometry, normals, texture coordinates and material of every face in leaf order, material
+// records and texels, lights, camera, resolution, Morton domain.  Version 2 of the tag (version 1 hashed three counts).
 static uint64_t scene_tag(const Scene& s)
 {
-    return (uint64_t(s.faces.size()) * 0x9E3779B97F4A7C15ull) ^ (uint64_t(s.materials.size()) << 40) ^ (uint64_t(s.lights.size()) << 52);
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    auto mixd = [&](double v) { mix(&v, sizeof v); };
+    auto mixi = [&](int64_t v) { mix(&v, sizeof v); };
+    mixi(2); mixi(int64_t(s.faces.size())); mixi(int64_t(s.materials.size())); mixi(int64_t(s.lights.size()));
+    for (const FaceRec& f : s.faces) {
+        for (int c = 0; c < 3; c++) { mixd(f.v[c].x); mixd(f.v[c].y); mixd(f.v[c].z); mixd(f.vn[c].x); mixd(f.vn[c].y); mixd(f.vn[c].z); mixd(f.vt[c][0]); mixd(f.vt[c][1]); }
+        mixi(f.material); mixi(f.morton);
+    }
+    for (const MaterialRec& m : s.materials) {
+        mixd(m.kd.x); mixd(m.kd.y); mixd(m.kd.z); mixd(m.ks.x); mixd(m.ks.y); mixd(m.ks.z); mixd(m.Ns); mixd(m.Ni);
+        mixi(m.has_map); mixi(m.map_w); mixi(m.map_h);
+        if (!m.bgr.empty()) mix(m.bgr.data(), m.bgr.size());
+    }
+    for (const LightRec& l : s.lights) { mixi(l.material); mixd(l.radiance.x); mixd(l.radiance.y); mixd(l.radiance.z); }
+    for (const Vec3* v : {&s.eye, &s.look_at, &s.up}) { mixd(v->x); mixd(v->y); mixd(v->z); }
+    mixd(s.fovy); mixi(s.width); mixi(s.height);
+    for (int a = 0; a < 3; a++) { mixd(s.morton_lo[a]); mixd(s.morton_span[a]); }
+    return h;
 }
 
 int mcpt_checkpoint_save(const char* file, const mcpt_scene* h, const double* img, int32_t spp, uint64_t seed, int32_t parts, const uint8_t* done)
@@ -1135,8 +1189,16 @@ int mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, co
         std::printf("Total real = %d\nBuild BVH success\n", s.bi.Nr);
     }
     mcpt_device* dev = nullptr;
-    rc = mcpt_device_create(sc, o.device, &dev);
+    mcpt_multi* multi = nullptr;
+    const bool many = o.num_devices > 0 || o.num_devices == -1;
+    if (many) rc = mcpt_multi_create(sc, o.num_devices > 0 ? o.devices : nullptr, o.num_devices > 0 ? o.num_devices : 0, MCPT_BUILD_HOST, o.gather, &multi);
+    else rc = mcpt_device_create(sc, o.device, &dev);
     if (rc) { mcpt_scene_free(sc); return rc; }
+    if (talk && many) std::printf("rendering on %d GPUs\n", mcpt_multi_num_devices(multi));
+    if (many && o.checkpoint) {
+        mcpt_multi_free(multi); mcpt_scene_free(sc);
+        return fail(MCPT_ERR_ARG, "a checkpointed frame is rendered partition by partition on one GPU: leave num_devices at 0");
+    }
     const auto t1 = clk::now();
     if (talk) std::printf("Phase 1(read scene + bvh build) time cost = %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
     std::vector<double> img(size_t(s.width) * s.height * 3, 0.0);
@@ -1144,7 +1206,7 @@ int mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, co
     rp.spp = spp; rp.seed = o.seed; rp.world = 1;
     mcpt_stats local{};
     if (!o.checkpoint) {
-        rc = mcpt_render(dev, &rp, img.data(), &local);
+        rc = many ? mcpt_multi_render(multi, &rp, img.data(), &local) : mcpt_render(dev, &rp, img.data(), &local);
     } else {
         // the frame in `parts` tile partitions, saved after each; partitions a matching checkpoint already holds are skipped
         const int parts = o.checkpoint_parts > 0 ? o.checkpoint_parts : 8;
@@ -1184,7 +1246,8 @@ int mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, co
         if (rc == MCPT_OK && (o.output_flags & MCPT_OUT_PFM)) rc = mcpt_write_pfm((stem + ".pfm").c_str(), img.data(), s.width, s.height);
     }
     if (stats) *stats = local;
-    mcpt_device_free(dev);
+    if (dev) mcpt_device_free(dev);
+    if (multi) mcpt_multi_free(multi);
     mcpt_scene_free(sc);
     return rc;
 }

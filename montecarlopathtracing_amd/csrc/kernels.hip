@@ -219,15 +219,26 @@ __global__ void k_fold_samples(const double* __restrict__ rad, const int32_t* __
     img[(size_t)pix * 3 + c] = (double)acc;
 }
 
+// End-of-frame exchange of the multi-GPU entry (multi_device.cpp): a rank's pixels leave its frame as one compact buffer
+// (pack, on the rank's GPU) and are put at their frame positions on GPU 0 (unpack).  One lane per (pixel, channel).
+__global__ void k_pack_pixels(const double* __restrict__ frame, const int32_t* __restrict__ pixels, long long n3, double* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) out[i] = frame[(size_t)pixels[i / 3] * 3 + (i % 3)];
+}
+__global__ void k_unpack_pixels(const double* __restrict__ in, const int32_t* __restrict__ pixels, long long n3, double* __restrict__ frame)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) frame[(size_t)pixels[i / 3] * 3 + (i % 3)] = in[i];
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static inline unsigned blocks_for(long long n, int block) { return (unsigned)((n + block - 1) / block); }
 
 template <class Src>
 static void launch_persistent(const DScene& S, const Src& src, long long total, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
-                              DCounters* ctr, hipStream_t st)
+                              DCounters* ctr, hipStream_t st, int grid)
 {
-    static int grid = 0;
-    if (!grid) grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<Src>));
     const long long blocks_needed = (total + 255) / 256;
     const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
@@ -235,9 +246,16 @@ static void launch_persistent(const DScene& S, const Src& src, long long total, 
     hipLaunchKernelGGL(k_trace_slow<Src>, dim3(256), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, ctr);
 }
 
+void init_launch_cfg_closest(LaunchCfg& cfg)
+{
+    cfg.array_grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<ArrayRaySource>), cfg.cus);
+    cfg.primary_grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<PrimaryRaySource>), cfg.cus);
+}
+
 // d_face, d_t, d_p must be non-null device buffers (the C-ABI layer always allocates them); d_pn may be null
 void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long long n, int32_t* d_face, double* d_t, double* d_p,
-                          double* d_pn, DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st)
+                          double* d_pn, DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st,
+                          const LaunchCfg& cfg)
 {
     if (n <= 0) return;
     if (!fast) {
@@ -245,15 +263,25 @@ void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long
         return;
     }
     ArrayRaySource src; src.rays = d_rays; src.n = n; src.leaf_out = d_face; src.t_out = d_t; src.p_out = d_p;
-    launch_persistent(S, src, n, queue, slow_list, slow_cap, ctr, st);
+    launch_persistent(S, src, n, queue, slow_list, slow_cap, ctr, st, cfg.array_grid);
     hipLaunchKernelGGL(k_finish_hits, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, n, d_face, d_p, d_pn, ctr);
+}
+void launch_pack_pixels(const double* d_frame, const int32_t* d_pixels, long long n_pixels, double* d_out, hipStream_t st)
+{
+    if (n_pixels <= 0) return;
+    hipLaunchKernelGGL(k_pack_pixels, dim3(blocks_for(n_pixels * 3, 256)), dim3(256), 0, st, d_frame, d_pixels, n_pixels * 3, d_out);
+}
+void launch_unpack_pixels(const double* d_in, const int32_t* d_pixels, long long n_pixels, double* d_frame, hipStream_t st)
+{
+    if (n_pixels <= 0) return;
+    hipLaunchKernelGGL(k_unpack_pixels, dim3(blocks_for(n_pixels * 3, 256)), dim3(256), 0, st, d_in, d_pixels, n_pixels * 3, d_frame);
 }
 void launch_primary_dirs(const DCamera& cam, double* d_dirs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_primary_dirs, dim3(blocks_for(cam.height, 64)), dim3(64), 0, st, cam, d_dirs);
 }
 void launch_primary_hits(const DScene& S, bool fast, const double* d_dirs, const int32_t* d_pixels, int n_pixels, PrimaryHit* d_hits,
-                         DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st)
+                         DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st, const LaunchCfg& cfg)
 {
     if (n_pixels <= 0) return;
     if (!fast) {
@@ -262,7 +290,7 @@ void launch_primary_hits(const DScene& S, bool fast, const double* d_dirs, const
     }
     PrimaryRaySource src; src.dirs = d_dirs; src.pixels = d_pixels; src.n_pixels = n_pixels; src.hits = d_hits;
     src.eye[0] = S.cam.eye[0]; src.eye[1] = S.cam.eye[1]; src.eye[2] = S.cam.eye[2];
-    launch_persistent(S, src, n_pixels, queue, slow_list, slow_cap, ctr, st);
+    launch_persistent(S, src, n_pixels, queue, slow_list, slow_cap, ctr, st, cfg.primary_grid);
 }
 void launch_shade_samples(const DScene& S, unsigned long long seed, const double* d_dirs, const int32_t* d_pixels,
                           const PrimaryHit* d_hits, int first_slot, int n_slots, int spp, double* d_rad, DCounters* ctr, hipStream_t st)

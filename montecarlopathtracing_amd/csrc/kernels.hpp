@@ -15,11 +15,28 @@ struct PrimaryHit {                 // closest hit of a pixel's (sample-independ
 };
 
 struct TraceQueue;
+
+// Resident grid sizes and tuning knobs of the persistent kernels, per GPU: filled once by init_launch_cfg() while that device is
+// current (mcpt_device_create), carried by the mcpt_device -- nothing about a launch is process-wide, so one process can drive
+// several GPUs from several threads.
+struct LaunchCfg {
+    int cus = 0;
+    unsigned logic_first = 0, logic_rest = 0;       // k_wf_logic<true> / <false>
+    int trace_grid = 0, finish_grid = 0;            // k_wf_trace, k_wf_finish
+    int array_grid = 0, primary_grid = 0;           // k_trace_persistent<ArrayRaySource> / <PrimaryRaySource>
+    long long trace_block_rays = 2048;              // MCPT_TRACE_BLOCK_RAYS: a block of k_wf_trace is started per this many rays
+    int min_chunk = 256, max_chunk = 2048;          // MCPT_TRACE_MIN_CHUNK / MAX_CHUNK: ray slots per queue claim
+};
+void init_launch_cfg(LaunchCfg& cfg);               // wavefront.hip (calls init_launch_cfg_closest of kernels.hip)
+void init_launch_cfg_closest(LaunchCfg& cfg);
 void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long long n, int32_t* d_face, double* d_t, double* d_p,
-                          double* d_pn, DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st);
+                          double* d_pn, DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st,
+                          const LaunchCfg& cfg);
+void launch_pack_pixels(const double* d_frame, const int32_t* d_pixels, long long n_pixels, double* d_out, hipStream_t st);
+void launch_unpack_pixels(const double* d_in, const int32_t* d_pixels, long long n_pixels, double* d_frame, hipStream_t st);
 void launch_primary_dirs(const DCamera& cam, double* d_dirs, hipStream_t st);
 void launch_primary_hits(const DScene& S, bool fast, const double* d_dirs, const int32_t* d_pixels, int n_pixels, PrimaryHit* d_hits,
-                         DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st);
+                         DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st, const LaunchCfg& cfg);
 void launch_shade_samples(const DScene& S, unsigned long long seed, const double* d_dirs, const int32_t* d_pixels,
                           const PrimaryHit* d_hits, int first_slot, int n_slots, int spp, double* d_rad, DCounters* ctr, hipStream_t st);
 void launch_sample_radiance(const DScene& S, unsigned long long seed, const double* d_dirs, const int32_t* d_pix, const int32_t* d_k,

@@ -536,38 +536,53 @@ void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* su
     hipLaunchKernelGGL(k_primary_surface, dim3(grid_for(n_slots_upper, 256, 4096)), dim3(256), 0, st, S, a, surf);
 }
 
-int persistent_grid(const void* kernel);
-
 // A resident-size grid whose blocks stride over the paths: starting a block of this kernel is expensive (large kernarg,
 // 160+ VGPRs, scratch), so 768 long-lived blocks beat 16 k short ones by 15 % of a frame at N=1 and 30 % at one eighth
 // of a frame (measured: MCPT_LOGIC_GRID sweep).
-void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st)
+void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st, const LaunchCfg& cfg)
 {
     if (n_upper <= 0) return;
-    static const unsigned forced = [] { const char* e = std::getenv("MCPT_LOGIC_GRID"); return e ? unsigned(std::atoi(e)) : 0u; }();
-    static unsigned cap_first = 0, cap_rest = 0;
-    if (!cap_first) {
-        cap_first = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<true>)));
-        cap_rest = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<false>)));
-    }
     // small inputs get small grids (>= 1024 paths per block): every wave that starts costs a few atomics on shared counters
-    unsigned g = grid_for(n_upper, 1024, first ? cap_first : cap_rest);
+    unsigned g = grid_for(n_upper, 1024, first ? cfg.logic_first : cfg.logic_rest);
     if (first) hipLaunchKernelGGL(k_wf_logic<true>, dim3(g), dim3(256), 0, st, S, a);
     else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a);
 }
 
-int persistent_grid(const void* kernel)
+int persistent_grid(const void* kernel, int cus)
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
     return cus * per_cu;
+}
+
+// the current device's numbers (mcpt_device_create calls this once per device, with that device current)
+void init_launch_cfg(LaunchCfg& cfg)
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cfg.cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cfg.cus = prop.multiProcessorCount;
+    if (cfg.cus <= 0) cfg.cus = 256;
+    const char* e = std::getenv("MCPT_LOGIC_GRID");
+    const unsigned forced = e ? unsigned(std::atoi(e)) : 0u;
+    cfg.logic_first = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<true>), cfg.cus));
+    cfg.logic_rest = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<false>), cfg.cus));
+    cfg.trace_grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace), cfg.cus);
+    cfg.finish_grid = persistent_grid(reinterpret_cast<const void*>(k_wf_finish), cfg.cus);
+    // a wave that starts pays one atomic on the queue head and a few on the counters: give every block >= 2048 rays
+    e = std::getenv("MCPT_TRACE_BLOCK_RAYS");
+    long long v = e ? std::atoll(e) : 0;
+    cfg.trace_block_rays = v >= 256 ? v : 2048;
+    // every claim is an atomic on one word (~88 per microsecond on this chip): below this many rays per claim the queue head,
+    // not the walk, bounds a launch of a million rays
+    e = std::getenv("MCPT_TRACE_MIN_CHUNK");
+    int c = e ? std::atoi(e) : 0;
+    cfg.min_chunk = c >= 64 ? c / 64 * 64 : 256;
+    e = std::getenv("MCPT_TRACE_MAX_CHUNK");
+    c = e ? std::atoi(e) : 0;
+    cfg.max_chunk = c >= 64 ? c / 64 * 64 : 2048;
+    if (cfg.max_chunk < cfg.min_chunk) cfg.max_chunk = cfg.min_chunk;
+    init_launch_cfg_closest(cfg);
 }
 
 long long persistent_chunk(long long total, int grid_blocks)
@@ -581,7 +596,7 @@ long long persistent_chunk(long long total, int grid_blocks)
 }
 
 void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool fast, TraceQueue* queue, long long* slow_list,
-                     unsigned int slow_cap, hipStream_t st)
+                     unsigned int slow_cap, hipStream_t st, const LaunchCfg& cfg)
 {
     if (n_upper <= 0) return;
     const long long total = n_upper * (a.nl + 1);
@@ -589,27 +604,17 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
         hipLaunchKernelGGL(k_wf_trace_reference, dim3(grid_for(total, 256, 1u << 20)), dim3(256), 0, st, S, a);
         return;
     }
-    static int grid = 0;
-    if (!grid) grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace));
-    // a wave that starts pays one atomic on the queue head and a few on the counters: give every block >= 2048 rays
-    static const long long rays_per_block = [] { const char* e = std::getenv("MCPT_TRACE_BLOCK_RAYS"); const long long v = e ? std::atoll(e) : 0; return v >= 256 ? v : 2048; }();
-    const long long blocks_needed = (total + rays_per_block - 1) / rays_per_block;
-    const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
+    const long long blocks_needed = (total + cfg.trace_block_rays - 1) / cfg.trace_block_rays;
+    const int g = (int)(blocks_needed < cfg.trace_grid ? blocks_needed : cfg.trace_grid);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    // every claim is an atomic on one word (~88 per microsecond on this chip): below this many rays per claim the queue head,
-    // not the walk, bounds a launch of a million rays
-    static const int min_chunk = [] { const char* e = std::getenv("MCPT_TRACE_MIN_CHUNK"); const int v = e ? std::atoi(e) : 0; return v >= 64 ? v / 64 * 64 : 256; }();
-    static const int max_chunk = [] { const char* e = std::getenv("MCPT_TRACE_MAX_CHUNK"); const int v = e ? std::atoi(e) : 0; return v >= 64 ? v / 64 * 64 : 2048; }();
-    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, min_chunk, max_chunk < min_chunk ? min_chunk : max_chunk);
+    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
     hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 64 ? g : 64), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
 }
 
-void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st)
+void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st, const LaunchCfg& cfg)
 {
     if (n_upper <= 0) return;
-    static unsigned resident = 0;
-    if (!resident) resident = unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_finish)));
-    hipLaunchKernelGGL(k_wf_finish, dim3(grid_for(n_upper, 256, resident)), dim3(256), 0, st, S, a);
+    hipLaunchKernelGGL(k_wf_finish, dim3(grid_for(n_upper, 256, unsigned(cfg.finish_grid))), dim3(256), 0, st, S, a);
 }
 
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)

@@ -89,11 +89,11 @@ size_t wf_bytes_per_path(int nl);
 bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& a, WfState& b, WfRays& r);
 
 // n_upper: host-side upper bound of the input count (sizes the grid only)
-void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st);
+void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st, const LaunchCfg& cfg);
 void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool fast, TraceQueue* queue, long long* slow_list,
-                     unsigned int slow_cap, hipStream_t st);
-void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st);
-int persistent_grid(const void* kernel);
+                     unsigned int slow_cap, hipStream_t st, const LaunchCfg& cfg);
+void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st, const LaunchCfg& cfg);
+int persistent_grid(const void* kernel, int cus);   // blocks of 256 threads of `kernel` resident on the current device
 long long persistent_chunk(long long total, int grid_blocks);
 
 void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, int n_slots_upper, hipStream_t st);

@@ -50,7 +50,7 @@ class DistributedRenderer:
         self.tile_w, self.tile_h = tile_w, tile_h
         self.torch_device = torch_device
         i = scene.info
-        self.H, self.W = i.height, i.width
+        self.H, self.W = device.height, device.width      # the frame the device writes (fixed when it was created)
         self.frame = torch.zeros((self.H * self.W, 3), dtype=torch.float64, device=torch_device)
         self.pixel_lists = None
         self.counts = [self.H * self.W]

@@ -417,6 +417,76 @@ def test_fast_hierarchy_built_on_device(mcpt, oracle, name):
     dev.close()
 
 
+def test_multi_device_frame_equals_single_device(mcpt):
+    """mcpt_multi_* (the GPUs of a node behind one C-ABI call: a host thread per GPU, tiles dealt like rank/world, compact pixel
+    buffers gathered into the first GPU's HBM): the frame must equal mcpt_render's bit for bit whatever the number of ranks.
+    On a one-GPU box the ranks share GPU 0 -- three resident copies of the scene, three concurrent renders, two peer copies that
+    degenerate to device-to-device copies -- which exercises everything but the xGMI hop; with every visible GPU (one here) it
+    is the degenerate world of 1.  The RCCL form is created and torn down (ncclCommInitAll over the visible GPUs)."""
+    sc = mcpt.Scene(SCENES, "cornell-box", width=200, height=120)
+    dev = mcpt.Device(sc, 0)
+    st1 = mcpt.Stats()
+    want = dev.generateImg(8, seed=5, stats=st1)
+    dev.close()
+    for devices in (None, [0, 0, 0]):
+        md = mcpt.MultiDevice(sc, devices)
+        assert md.num_devices == (mcpt.device_count() if devices is None else 3)
+        st = mcpt.Stats()
+        got = md.generateImg(8, seed=5, stats=st)
+        again = md.generateImg(8, seed=5)
+        md.close()
+        assert np.array_equal(_bits(got), _bits(want)) and np.array_equal(_bits(again), _bits(want))
+        assert st.samples == st1.samples and st.rays_primary == st1.rays_primary
+        assert (st.rays_shadow + st.shadow_skipped, st.rays_bounce, st.shade_calls) == (st1.rays_shadow + st1.shadow_skipped, st1.rays_bounce, st1.shade_calls)
+    md = mcpt.MultiDevice(sc, list(range(mcpt.device_count())), gather=mcpt.GATHER_RCCL)
+    assert np.array_equal(_bits(md.generateImg(8, seed=5)), _bits(want))
+    md.close()
+    with pytest.raises(mcpt.McptError):
+        mcpt.MultiDevice(sc, [0, 0], gather=mcpt.GATHER_RCCL)          # RCCL wants distinct GPUs
+    with pytest.raises(mcpt.McptError):
+        sc.set_resolution(100, 60)                                     # a device was created from this scene
+    sc.close()
+
+
+def test_cpp_drop_in_render_scene(mcpt, tmp_path):
+    """The C++ surface a user of the reference switches to: a main() that includes include/mtpc_compat.hpp and calls
+    render_scene(path, filename, N) exactly like MTPC/MTPC.cpp:78, compiled here with g++ against libmcpt.so, and the mtpc
+    command-line stand-in.  Both must write the PNG the ctypes path writes, byte for byte -- also on "all GPUs"."""
+    import subprocess
+    csrc = os.path.join(ROOT, "montecarlopathtracing_amd", "csrc")
+    src = tmp_path / "main.cpp"
+    src.write_text('''#include "mtpc_compat.hpp"
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv)
+{
+    mtpc::options().seed = 9; mtpc::options().width = 96; mtpc::options().height = 64; mtpc::options().quiet = 1;
+    mtpc::options().output_prefix = argv[3];
+    if (argc > 4) mtpc::options().num_devices = std::atoi(argv[4]);
+    if (!render_scene(argv[1], argv[2], 6)) { std::fprintf(stderr, "%s\\n", mcpt_last_error()); return 1; }
+    return 0;
+}
+''')
+    exe = str(tmp_path / "dropin")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe, "-L" + csrc, "-lmcpt",
+                           "-Wl,-rpath," + csrc])
+    out = str(tmp_path) + os.sep
+    mcpt.render_scene(SCENES, "cornell-box", 6, seed=9, width=96, height=64, output_prefix=out + "py")
+    want = open(out + "py-SPP6.png", "rb").read()
+    subprocess.check_call([exe, SCENES, "cornell-box", out + "cpp"], cwd=str(tmp_path))
+    assert open(out + "cpp-SPP6.png", "rb").read() == want
+    subprocess.check_call([exe, SCENES, "cornell-box", out + "all", "-1"], cwd=str(tmp_path))
+    assert open(out + "all-SPP6.png", "rb").read() == want
+    mcpt.render_scene(SCENES, "cornell-box", 6, seed=9, width=96, height=64, output_prefix=out + "three", devices=[0, 0, 0])
+    assert open(out + "three-SPP6.png", "rb").read() == want
+    # the command-line stand-in for the reference's main(): it writes ../result/<filename>-SPP<N>.png relative to the cwd
+    run = tmp_path / "run"
+    run.mkdir()
+    (tmp_path / "result").mkdir()
+    subprocess.check_call([os.path.join(csrc, "mtpc"), SCENES, "cornell-box", "6", "9", "96", "64"], cwd=str(run), stdout=subprocess.DEVNULL)
+    assert open(str(tmp_path / "result" / "cornell-box-SPP6.png"), "rb").read() == want
+
+
 EDGE_MTL = "newmtl grey\nKd 0.6 0.5 0.4\nKs 0 0 0\nNs 1\nNi 1\nnewmtl lamp\nKd 0 0 0\nKs 0 0 0\nNs 1\nNi 1\n"
 EDGE_OBJ_HEAD = ("v -2 0 -2\nv 2 0 -2\nv 2 0 2\nv -2 0 2\nv -0.5 1.9 -0.5\nv 0.5 1.9 -0.5\nv 0.5 1.9 0.5\nv -0.5 1.9 0.5\n"
                  "vn 0 1 0\nvn 0 -1 0\nvt 0 0\n")

@@ -182,3 +182,35 @@ def test_parallel_host_build_equals_serial(mcpt, monkeypatch):
     ser = sc.fast_bvh_stats()
     assert par[0] == ser[0] and par[1] == ser[1] and par[3] and ser[3]
     assert np.array_equal(par[2], ser[2])
+
+
+def test_checkpoint_belongs_to_one_frame_only(mcpt, tmp_path):
+    """A checkpoint names its frame by everything the picture depends on (geometry, materials and texels, lights, camera,
+    resolution), not by counts: the same scene with the camera moved, or one vertex nudged, must not be resumed from it."""
+    import shutil
+    d = str(tmp_path) + os.sep
+    for ext in (".obj", ".mtl", ".camera"):
+        shutil.copy(SCENES + "veach-mis" + ext, d + "veach-mis" + ext)
+    sc = mcpt.Scene(d, "veach-mis", width=32, height=24)
+    img = np.arange(32 * 24 * 3, dtype=np.float64).reshape(24, 32, 3)
+    ck = d + "f.ckp"
+    mcpt.checkpoint_save(ck, sc, img, 4, 7, np.array([1, 0], dtype=np.uint8))
+    got, done = mcpt.checkpoint_load(ck, sc, 4, 7, 2)
+    assert np.array_equal(got, img) and done.tolist() == [1, 0]
+    cam = open(d + "veach-mis.camera").read().replace("eye 0.0 2.0 15.0", "eye 0.0 2.0 15.5")
+    open(d + "veach-mis.camera", "w").write(cam)
+    moved = mcpt.Scene(d, "veach-mis", width=32, height=24)
+    with pytest.raises(mcpt.McptError) as e:
+        mcpt.checkpoint_load(ck, moved, 4, 7, 2)
+    assert e.value.code == -2
+    lines = open(d + "veach-mis.obj").read().split("\n")
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("v "))
+    x, y, z = lines[k].split()[1:4]
+    lines[k] = "v %s %s %.9f" % (x, y, float(z) + 1e-6)
+    open(d + "veach-mis.obj", "w").write("\n".join(lines))
+    open(d + "veach-mis.camera", "w").write(cam.replace("eye 0.0 2.0 15.5", "eye 0.0 2.0 15.0"))
+    nudged = mcpt.Scene(d, "veach-mis", width=32, height=24)
+    assert nudged.info.num_faces == sc.info.num_faces
+    with pytest.raises(mcpt.McptError) as e:
+        mcpt.checkpoint_load(ck, nudged, 4, 7, 2)
+    assert e.value.code == -2

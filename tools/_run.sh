@@ -1,3 +1,3 @@
-bash tools/_bench_variants.sh gpurun_out/r2e default nocull26 cull26
-MCPT_LIB=$PWD/montecarlopathtracing_amd/csrc/variants/libmcpt_cull26.so python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "closest_hit or bulk or overflow or edge or pipelines or wavefront_iterations or image_matches" > gpurun_out/r2e/tests.log 2>&1 || { tail -40 gpurun_out/r2e/tests.log; exit 1; }
-tail -3 gpurun_out/r2e/tests.log
+mkdir -p gpurun_out/r2f
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "multi_device or cpp_drop_in or render_scene_outputs" > gpurun_out/r2f/tests.log 2>&1 || { tail -60 gpurun_out/r2f/tests.log; exit 1; }
+tail -3 gpurun_out/r2f/tests.log
