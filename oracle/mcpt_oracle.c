@@ -834,11 +834,13 @@ static NextRay next_ray(const Ctx* c, int depth, const Hit* p, const Material* m
         if (fresnel < U(c, depth, SLOT_FRESNEL(nl))) {
             if (refract_dir(vneg(dir), normal, n1 / n2, &direction)) {
                 out.o = p->p; out.d = direction; out.type = RT_TRANSMISSION;
+                if (c->st) c->st->rays_on_surface++;
                 return out;
             } else {
                 vec3 incoming = vneg(dir);
                 vec3 reflect = vsub(incoming, vmul(vmul(normal, vdot(incoming, normal)), 2));
                 out.o = p->p; out.d = reflect; out.type = RT_SPECULAR;
+                if (c->st) c->st->rays_on_surface++;
                 return out;
             }
         }
@@ -1043,6 +1045,7 @@ static void stats_add(orc_stats* a, const orc_stats* b)
     a->rays_primary += b->rays_primary; a->rays_shadow += b->rays_shadow; a->rays_bounce += b->rays_bounce;
     a->box_tests += b->box_tests; a->tri_tests += b->tri_tests; a->shade_calls += b->shade_calls; a->samples += b->samples;
     if (b->max_depth > a->max_depth) a->max_depth = b->max_depth;
+    a->rays_on_surface += b->rays_on_surface;
 }
 
 /* generateImg, MTPC/pathTracing.cpp:274-331 (D1, D3) */

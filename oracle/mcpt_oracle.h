@@ -65,6 +65,7 @@ typedef struct {
     uint64_t rays_primary, rays_shadow, rays_bounce;
     uint64_t box_tests, tri_tests, shade_calls, samples;
     int max_depth;
+    uint64_t rays_on_surface;   /* bounce rays that start on the surface itself: refraction / total reflection (pathTracing.cpp:102,109) */
 } orc_stats;
 
 /* ---- RNG seam (D1) ---- */

@@ -23,7 +23,7 @@ class BvhInfo(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_shadow", "rays_bounce", "box_tests",
-                                           "tri_tests", "shade_calls", "samples")] + [("max_depth", C.c_int)]
+                                           "tri_tests", "shade_calls", "samples")] + [("max_depth", C.c_int), ("rays_on_surface", C.c_uint64)]
 
     @property
     def rays(self):

@@ -16,11 +16,15 @@ from conftest import ROOT  # noqa: E402
 
 REL_TOL = 1e-9
 
-# Discrete flips.  The reference starts refraction / total-internal-reflection rays exactly on the surface they leave
-# (pathTracing.cpp:102,109: no 0.01 offset), so whether such a ray re-hits its own triangle is decided by the sign of a t_x
-# that is pure rounding noise -- any last-bit difference upstream (device libm vs glibc) flips it.  Scenes without Ni > 1
-# only flip when a uniform lands within an ulp of a threshold.
-FLIP_BUDGET = {"cornell-box": 1e-4, "veach-mis": 1e-4, "glassroom": 1e-2, "interior": 1e-2}
+# Discrete flips, MEASURED (tools/flip_probe.py, 40 000 random camera samples per scene, 160x90): cornell-box 0, veach-mis 0,
+# glassroom 22, interior 6 -- and every one of those 28 sits on a path with a ray that starts ON the surface it leaves: the
+# reference gives refraction / total-reflection rays no 0.01 offset (pathTracing.cpp:102,109), so whether such a ray re-hits its
+# own triangle is decided by the sign of a t_x that is pure rounding noise, and a last-bit difference upstream (device libm vs
+# glibc) flips it: 22 of 1 289 such paths in glassroom (1.7 %), 6 of 674 in interior (0.9 %).  Paths without such a ray: 0 flips in
+# 158 000.  Budgets = 2 x observed: per sample of the whole scene (images), per path with an on-surface ray (sample test).
+FLIP_BUDGET = {"cornell-box": 2.5e-5, "veach-mis": 2.5e-5, "glassroom": 1.1e-3, "interior": 3e-4}
+ON_SURFACE_FLIP_RATE = 0.035        # of the paths that have an on-surface ray
+OTHER_FLIP_RATE = 2.5e-5            # of all other paths (none observed)
 
 
 def _bits(a):
@@ -128,17 +132,26 @@ def test_deferred_ray_list_overflow(oracle, mcpt, monkeypatch):
 def test_sample_radiance(pair, oracle, mcpt):
     name, osc, sc, dev = pair
     rng = np.random.default_rng(5)
-    n = 3000
+    n = 6000
     pix = rng.integers(0, osc.width * osc.height, size=n).astype(np.int32)
     k = rng.integers(0, 64, size=n).astype(np.int32)
     g = dev.sample_radiance(77, pix, k)
-    o = np.array([osc.sample_radiance(77, int(p // osc.width), int(p % osc.width), int(kk)) for p, kk in zip(pix, k)])
+    o = np.zeros((n, 3))
+    on_surface = np.zeros(n, dtype=bool)            # the path has a refraction / total-reflection ray (starts on the surface)
+    for i, (p, kk) in enumerate(zip(pix, k)):
+        st = oracle.Stats()
+        o[i] = osc.sample_radiance(77, int(p // osc.width), int(p % osc.width), int(kk), stats=st)
+        on_surface[i] = st.rays_on_surface > 0
     scale = np.maximum(np.abs(o).max(axis=1), 1e-12)
     err = np.abs(g - o).max(axis=1) / scale
-    flips = int((err > REL_TOL).sum())
-    assert flips <= max(1, int(n * FLIP_BUDGET[name]) + 1), "radiance mismatch on %d/%d samples (max rel %.3e)" % (flips, n, err.max())
+    flip = err > REL_TOL
+    assert int((flip & ~on_surface).sum()) <= int(n * OTHER_FLIP_RATE), "radiance mismatch on %d ordinary samples (max rel %.3e)" % (
+        int((flip & ~on_surface).sum()), err[~on_surface].max())
+    assert int((flip & on_surface).sum()) <= max(2, int(on_surface.sum() * ON_SURFACE_FLIP_RATE) + 1), (int((flip & on_surface).sum()), int(on_surface.sum()))
+    if name in ("glassroom", "interior"):
+        assert on_surface.sum() > 50
     assert np.abs(o).sum() > 0
-    same = err <= REL_TOL
+    same = ~flip
     assert abs(g[same].sum() - o[same].sum()) <= 1e-9 * abs(o[same]).sum()
 
 
@@ -154,10 +167,10 @@ def test_image_matches_oracle(pair, oracle, mcpt, pipeline):
     scale = np.maximum(np.abs(ref), 1e-6)
     rel = np.abs(img - ref) / scale
     bad = int((rel > 1e-6).sum())      # float accumulator: 1 ulp of fp32 ~ 6e-8
-    budget = max(3, int(img.size * spp * FLIP_BUDGET[name] * 0.5))
+    budget = max(3, int(img.size * spp * FLIP_BUDGET[name]))      # img.size counts channels: 3 per flipped sample
     assert bad <= budget, "%d pixel channels differ (max rel %.3e)" % (bad, rel.max())
     # a flipped sample can be a firefly (radiance / 0.6^depth): the image mean moves with the flip budget
-    assert abs(img.mean() - ref.mean()) <= (3e-2 if FLIP_BUDGET[name] > 1e-3 else 2e-3) * ref.mean()
+    assert abs(img.mean() - ref.mean()) <= (2e-3 + 25 * FLIP_BUDGET[name]) * ref.mean()
     assert (rel <= 1e-6).mean() >= 0.97
     if name not in ("glassroom", "interior"):   # same work was done (a flipped path does different work)
         assert st.rays_shadow + st.shadow_skipped == ost.rays_shadow and st.rays_bounce == ost.rays_bounce
@@ -228,7 +241,7 @@ def test_wavefront_iterations_against_megakernel_and_oracle(pair, oracle, mcpt, 
         ref = osc.render(spp, seed=3)
         rel = np.abs(a - ref) / np.maximum(np.abs(ref), 1e-6)
         bad = int((rel > 1e-6).sum())
-        assert bad <= max(3, int(a.size * spp * FLIP_BUDGET[name] * 0.5)), "%d pixel channels differ from the oracle" % bad
+        assert bad <= max(3, int(a.size * spp * FLIP_BUDGET[name])), "%d pixel channels differ from the oracle" % bad
     finally:
         dev.close()
 
@@ -564,21 +577,32 @@ def test_bench_line_keeps_its_contract(tmp_path):
     assert d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert (r["bytes_per_unit"]["node_visit"], r["bytes_per_unit"]["triangle_test"], r["bytes_per_unit"]["ray"]) == (32, 48, 64)
+    assert r["record_bytes_rate_GBs"] > r["achieved"] and r["traffic"] is None      # not the headline workload: nothing measured to quote
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
 
 
-@pytest.mark.parametrize("name,spp", [("cornell-box", 256), ("veach-mis", 100)])
-def test_full_size_frame_properties(mcpt, monkeypatch, name, spp):
-    """BASELINE's own frames (configs 2 and 3: cornell-box 1280x720 SPP 256, veach-mis SPP 100), which the oracle cannot finish in seconds, through properties that do
+@pytest.mark.parametrize("name,spp", [("cornell-box", 256), ("veach-mis", 100), ("interior", 256)])
+def test_full_size_frame_properties(mcpt, monkeypatch, name, spp, tmp_path):
+    """BASELINE's own frames (configs 2, 3 and 4: cornell-box 1280x720 SPP 256, veach-mis SPP 100, and the generated textured
+    interior of 204 k triangles that stands in for the unshipped bedroom scene, SPP 256), which the oracle cannot finish in
+    seconds, through properties that do
     not depend on size: rendering it again gives the same bits; the 8-rank tile partition assembles to the same bits; a frame
     cut into chunks by a small workspace gives the same bits; its mean agrees with an independent seed's within Monte-Carlo
     error; every ray the statistics count was traced (samples = pixels x SPP, rays = shadow + bounce)."""
     import bench
-    d = bench.write_scene_dir(name, 1280, 720)
+    if name == "interior":
+        from montecarlopathtracing_amd import synthetic
+        d = str(tmp_path) + os.sep
+        synthetic.write_interior(d, "interior", width=1280, height=720)
+    else:
+        d = bench.write_scene_dir(name, 1280, 720)
     monkeypatch.delenv("MCPT_WORKSPACE_GB", raising=False)
     sc = mcpt.Scene(d, name)
+    if name == "interior":
+        assert sc.info.num_faces > 200000
     dev = mcpt.Device(sc, 0)
     st = mcpt.Stats()
     full = dev.generateImg(spp, seed=0, stats=st)
@@ -602,6 +626,32 @@ def test_full_size_frame_properties(mcpt, monkeypatch, name, spp):
     assert np.array_equal(_bits(full), _bits(chunked))
     small.close()
     sc.close()
+
+
+def test_config5_frame_at_its_own_size(mcpt):
+    """BASELINE config 5 as it is written: the synthetic 10 M-triangle scene (reference structures built on the GPU) at 3840x2160,
+    SPP 1024 -- 8.5 G camera samples, ~24 s per frame on one MI355X, path state streamed through HBM in ~20 chunks.  The frame is
+    rendered once whole and once as the 8 tile partitions an 8-GPU node would render; both must give the same bits, every sample and
+    ray must be accounted for, and the picture must be a picture (lit, not saturated)."""
+    from montecarlopathtracing_amd import synthetic
+    sc = synthetic.make_scene(mcpt, 10_000_000, defer_build=True, width=3840, height=2160)
+    assert sc.info.num_faces >= 10_000_000
+    dev = mcpt.Device(sc, 0)
+    st = mcpt.Stats()
+    full = dev.generateImg(1024, seed=0, stats=st)
+    assert st.samples == 3840 * 2160 * 1024 and st.rays_primary == 3840 * 2160
+    assert st.rays_shadow > st.samples // 4 and st.rays_bounce > st.samples // 8
+    parts = np.zeros_like(full)
+    rays = 0
+    for r in range(8):
+        s8 = mcpt.Stats()
+        dev.generateImg(1024, seed=0, rank=r, world=8, img=parts, stats=s8)
+        rays += s8.rays_shadow + s8.rays_bounce
+    assert np.array_equal(_bits(full), _bits(parts))
+    assert rays == st.rays_shadow + st.rays_bounce
+    q = mcpt.imshow_rgb8(full)
+    assert 10 < q.mean() < 245 and (q > 0).mean() > 0.5
+    dev.close(); sc.close()
 
 
 def test_ten_million_triangles(mcpt):

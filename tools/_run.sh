@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r2f
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "multi_device or cpp_drop_in or render_scene_outputs" > gpurun_out/r2f/tests.log 2>&1 || { tail -60 gpurun_out/r2f/tests.log; exit 1; }
-tail -3 gpurun_out/r2f/tests.log
+mkdir -p gpurun_out/r2g
+python tools/flip_probe.py 40000 > gpurun_out/r2g/flips.txt 2>&1; cat gpurun_out/r2g/flips.txt | head -8
