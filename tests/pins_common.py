@@ -13,6 +13,13 @@ tests/golden/make_golden.py from the reference's files.
     16x16 block and channel: z = (published block mean - our block mean) / sigma, where our mean comes from two independent
     renders at the published SPP and native resolution (same pixels, same quantisation) and sigma^2 = 1.5 x the block-mean
     variance estimated from the per-pixel differences of those two renders.  If the restatement is right the z are N(0,1).
+    One thing is NOT shared with the reference by design (D1): its four RNG engines are read and advanced without a lock by the
+    8 OpenMP threads that render one pixel's samples (MTPC/pathTracing.cpp:5,32,68,169,303), so samples of a pixel repeat draws and
+    are positively correlated; ours are independent.  The expectation of a sample is the same, the spread of a pixel's mean is not,
+    and imshow's clamp at 255 turns a wider spread into a darker expectation.  It shows exactly where it must: veach-mis blocks
+    with no saturated pixel agree to 0.01-0.1 % (z mean 0.00-0.06), blocks in which 10-50 % of the pixels saturate are 0.5 %
+    darker in the published SPP-10 render and 0.1 % darker at SPP 100 (a 10x narrower spread).  The z test therefore runs on
+    blocks the clamp leaves alone (level < 140 of 255: < 1 % saturated pixels); the others are held to a one-sided band.
 """
 import os
 
@@ -62,12 +69,12 @@ def check_emitter_pixels(emit, scene):
 
 def block_stats(name, q_a, q_b, block_step=1):
     """q_a, q_b: [H, W, 3] uint8 quantised renders of two seeds at the published SPP (only the selected blocks need to be
-    filled).  Returns (diff [n, 3] = published block mean - ours, sigma [n, 3] of that difference) over the blocks (br, bc)
-    with br % step == bc % step == 0."""
+    filled).  Returns (diff [n, 3] = published block mean - ours, sigma [n, 3] of that difference, ours [n, 3], sat [n] = share of
+    saturated pixel channels in our two renders) over the blocks (br, bc) with br % step == bc % step == 0."""
     pub, (w, h, rows) = published_blocks(name)
     a = q_a.astype(np.float64)
     b = q_b.astype(np.float64)
-    diff, sigma = [], []
+    diff, sigma, ours, sat = [], [], [], []
     npx = BLOCK * BLOCK
     for br in range(0, rows // BLOCK, block_step):
         for bc in range(0, w // BLOCK, block_step):
@@ -77,7 +84,9 @@ def block_stats(name, q_a, q_b, block_step=1):
             e = (a[sl] + b[sl]).mean(axis=(0, 1)) / 2
             diff.append(pub[br, bc].astype(np.float64) - e)
             sigma.append(np.sqrt(1.5 * var_blk))                                  # published run + the mean of our two
-    return np.array(diff), np.array(sigma)
+            ours.append(e)
+            sat.append(((a[sl] >= 255).mean() + (b[sl] >= 255).mean()) / 2)
+    return np.array(diff), np.array(sigma), np.array(ours), np.array(sat)
 
 
 def selected_blocks(name, block_step):
@@ -85,13 +94,10 @@ def selected_blocks(name, block_step):
     return [(br, bc) for br in range(0, rows // BLOCK, block_step) for bc in range(0, w // BLOCK, block_step)]
 
 
-def assert_standard_normal(diff, sigma, what, mean_tol=0.2, rms=(0.8, 1.25), tail=0.01, drop_saturated=False):
-    """Block z-scores are N(0,1) when both sides sample the same expectation.  Pixels that saturate make a few blocks
-    heavy-tailed, hence clipped moments and a counted tail; `whole` is the z-score of the summed difference per channel
-    (the picture's brightness), which no per-block weighting can bias."""
-    if drop_saturated:                      # blocks at 255 on every side carry no information
-        keep = np.abs(diff).max(axis=1) > 0
-        diff, sigma = diff[keep], sigma[keep]
+def assert_standard_normal(diff, sigma, what, mean_tol=0.2, rms=(0.8, 1.25), tail=0.01):
+    """Block z-scores are N(0,1) when both sides sample the same expectation.  A few blocks are heavy-tailed (fireflies), hence
+    clipped moments and a counted tail; `whole` is the z-score of the summed difference per channel (the picture's brightness),
+    which no per-block weighting can bias."""
     z = diff / sigma
     zc = np.clip(z, -6, 6)
     m, r, t = float(zc.mean()), float(np.sqrt((zc ** 2).mean())), float((np.abs(z) > 4).mean())
@@ -102,4 +108,20 @@ def assert_standard_normal(diff, sigma, what, mean_tol=0.2, rms=(0.8, 1.25), tai
     assert rms[0] < r < rms[1], msg
     assert t < tail, msg
     assert np.abs(whole).max() < 4.0, msg
+    return msg
+
+
+def assert_matches_published(name, q_a, q_b, what, block_step=1, clamp_band=(-0.012, 0.004), **kw):
+    """The z test on the blocks the clamp leaves alone, the one-sided band on the rest (module docstring): the published render may
+    be darker there by up to 1.2 % of the blocks' brightness, not brighter.  "Left alone" = the block's level, averaged over the
+    published and our renders (a selection symmetric in the two sides, so it cannot bias their difference), is below 140 of 255:
+    such blocks have < 1 % saturated pixels."""
+    diff, sigma, ours, sat = block_stats(name, q_a, q_b, block_step)
+    free = (ours + diff / 2).max(axis=1) < 140.0
+    msg = assert_standard_normal(diff[free], sigma[free], what + " (blocks below level 140: %d of %d)" % (free.sum(), free.size), **kw)
+    rest = ~free & (np.abs(diff).max(axis=1) > 0)
+    if rest.sum() >= 20:
+        rel = float(diff[rest].sum() / ours[rest].sum())
+        msg += "; %d blocks with saturating pixels: published %+.2f %%" % (rest.sum(), 100 * rel)
+        assert clamp_band[0] < rel < clamp_band[1], msg
     return msg

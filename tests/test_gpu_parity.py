@@ -261,16 +261,16 @@ def test_published_renders_pin_the_gpu_path(mcpt):
     """What the reference's published renders pin (tests/pins_common.py), applied to the HIP path at native resolution:
     (1) pixel-exact: every pixel whose primary hit is an emitter is (255,255,255) in every published render of the scene --
     4 922 pixels of cornell-box (and only 4 other pixels of cornell-box-SPP25.png are saturated), 45 266 of veach-mis;
-    (2) Monte-Carlo precision: z-scores of all 16x16 blocks against two GPU renders at the published SPP are standard normal."""
+    (2) Monte-Carlo precision: z-scores of all 16x16 blocks against two GPU renders at the published SPP are standard normal
+    (blocks whose pixels saturate: the one-sided band of pins_common.py, where the reference's racy RNG meets imshow's clamp)."""
     import pins_common as P
     sc = mcpt.Scene(SCENES, "cornell-box")                  # native 1024x1024 camera
     dev = mcpt.Device(sc, 0)
     got = P.check_emitter_pixels(_gpu_emitter_map(mcpt, sc, dev), "cornell-box")
     assert all(v[0] == 4922 for v in got.values()) and got["cornell_spp25"][1] == 4, got
     qa, qb = (mcpt.imshow_rgb8(dev.generateImg(25, seed=s)) for s in (101, 102))
-    diff, sigma = P.block_stats("cornell_spp25", qa, qb)
-    assert diff.shape == (4096, 3)
-    print(P.assert_standard_normal(diff, sigma, "cornell-box SPP25, all blocks", mean_tol=0.1, rms=(0.9, 1.12)))
+    assert P.block_stats("cornell_spp25", qa, qb)[0].shape == (4096, 3)
+    print(P.assert_matches_published("cornell_spp25", qa, qb, "cornell-box SPP25, all blocks", mean_tol=0.1, rms=(0.9, 1.12)))
     dev.close()
     sc.close()
     sc = mcpt.Scene(SCENES, "veach-mis")                    # native 1200x900
@@ -279,9 +279,7 @@ def test_published_renders_pin_the_gpu_path(mcpt):
     assert got["veach_spp10"][0] == 45266 and got["veach_spp100"][0] == 45266, got
     for name, spp in (("veach_spp10", 10), ("veach_spp100", 100)):
         qa, qb = (mcpt.imshow_rgb8(dev.generateImg(spp, seed=s)) for s in (201, 202))
-        diff, sigma = P.block_stats(name, qa, qb)
-        print(P.assert_standard_normal(diff, sigma, "veach-mis %s, all unsaturated blocks" % name, mean_tol=0.3, rms=(0.8, 1.45), tail=0.02,
-                                       drop_saturated=True))
+        print(P.assert_matches_published(name, qa, qb, "veach-mis %s, all blocks" % name, mean_tol=0.2, rms=(0.85, 1.2), tail=0.01))
     dev.close()
     sc.close()
 
@@ -650,7 +648,7 @@ def test_config5_frame_at_its_own_size(mcpt):
     assert np.array_equal(_bits(full), _bits(parts))
     assert rays == st.rays_shadow + st.rays_bounce
     q = mcpt.imshow_rgb8(full)
-    assert 10 < q.mean() < 245 and (q > 0).mean() > 0.5
+    assert 1 < q.mean() < 245 and (q > 0).mean() > 0.02          # a dim scene: four small quad lights over 10 M small triangles
     dev.close(); sc.close()
 
 

@@ -151,18 +151,17 @@ def test_cornell_matches_published_render_at_monte_carlo_precision(oracle):
     resolves a 0.2 % difference in brightness; a wrong tie-break that moves a silhouette or a missing weight is far above that."""
     s = oracle.OracleScene(SCENES + "cornell-box", texture_dir=SCENES)
     a, b = _oracle_blocks(oracle, s, "cornell_spp25", 25, 4, (11, 12))
-    diff, sigma = P.block_stats("cornell_spp25", a, b, 4)
-    assert diff.shape == (256, 3)
-    print(P.assert_standard_normal(diff, sigma, "cornell-box SPP25"))
+    assert P.block_stats("cornell_spp25", a, b, 4)[0].shape == (256, 3)
+    print(P.assert_matches_published("cornell_spp25", a, b, "cornell-box SPP25", 4))
 
 
 def test_veach_matches_published_render_at_monte_carlo_precision(oracle):
     """veach-mis exercises five lights, the frozen light-area distribution (Q1: without it lights 2-5 are sampled over their
-    whole area and the picture changes materially) and the Phong lobe.  SPP 10, every 5th block, native resolution."""
+    whole area and the picture changes materially) and the Phong lobe.  SPP 10, every 5th block, native resolution; blocks
+    whose pixels saturate are held to the one-sided band of pins_common.py (the reference's racy RNG, D1, meets imshow's clamp)."""
     s = oracle.OracleScene(SCENES + "veach-mis", texture_dir=SCENES)
     a, b = _oracle_blocks(oracle, s, "veach_spp10", 10, 5, (21, 22))
-    diff, sigma = P.block_stats("veach_spp10", a, b, 5)
-    print(P.assert_standard_normal(diff, sigma, "veach-mis SPP10", mean_tol=0.45, rms=(0.8, 1.45), tail=0.02, drop_saturated=True))
+    print(P.assert_matches_published("veach_spp10", a, b, "veach-mis SPP10", 5, mean_tol=0.35, rms=(0.75, 1.35), tail=0.02, clamp_band=(-0.02, 0.01)))
 
 
 def test_config1_cornell_400x400_spp2(oracle, tmp_path):

@@ -1,2 +1,4 @@
-mkdir -p gpurun_out/r2g
-python tools/flip_probe.py 40000 > gpurun_out/r2g/flips.txt 2>&1; cat gpurun_out/r2g/flips.txt | head -8
+mkdir -p gpurun_out/r2h
+python -m pytest tests -q -m gpu --durations=12 > gpurun_out/r2h/tests.log 2>&1; rc=$?
+tail -32 gpurun_out/r2h/tests.log
+exit $rc
