@@ -38,6 +38,13 @@ namespace mcpt {
 #ifndef MCPT_INNER_BURST
 #define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
 #endif
+#ifndef MCPT_TRI_SHARE
+#define MCPT_TRI_SHARE 0            /* 1: the triangle phase hands the pending (ray, triangle) pairs of all its lanes out to all 64 lanes
+                                       (a lane with a 4-triangle leaf gets three helpers) instead of every lane walking its own leaf one
+                                       triangle per iteration at ~28 of 64 lanes.  Measured, not kept: triangle iterations 79.5 M -> 51.0 M
+                                       per frame (all iterations -16 %), but the ~45 cross-lane moves per iteration and 24 spilled
+                                       registers make one such iteration 1.75x as long: 7.75 instead of 6.27 ms per launch. */
+#endif
 #ifndef MCPT_POP_CULL
 #define MCPT_POP_CULL 0             /* 1: every stack entry carries a lower bound of its entry distance (16 bits: the upper half of the
                                        fp32 bound, i.e. rounded down); an entry popped after the ray's limit has moved in front of it is
@@ -62,7 +69,7 @@ namespace mcpt {
 //   stage 2: when the LDS batch is used up, stage 1 is written to LDS ([component][lane], 52 B per ray) and the following
 //            64 slots are requested at once; idle lanes take entries of the LDS batch by ballot rank.
 #define MCPT_RAYBUF_DOUBLES 6
-#define MCPT_RAYBUF_BYTES (64 * (MCPT_RAYBUF_DOUBLES * 8 + 4))      /* per wave */
+#define MCPT_RAYBUF_BYTES (64 * (MCPT_RAYBUF_DOUBLES * 8 + 4 + 4))  /* per wave: 64 rays, their flags, and the owner table of MCPT_TRI_SHARE */
 
 template <class Src>
 __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src, TraceQueue* queue, long long* __restrict__ slow_list,
@@ -80,6 +87,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int* __restrict__ rayflag = reinterpret_cast<int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
+    int* __restrict__ owner_of = rayflag + 64;      // MCPT_TRI_SHARE: pair slot -> owning lane | (triangle offset << 8)
 
     // wave-uniform supply state
     long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk
@@ -104,6 +112,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     // best.t holds the product (p.x - o.x) * (1 / d.x) of the leading candidate (within 2^-50 of its t_k), best.leaf its slot in
     // the fast triangle array; the candidate is verified (own box) and t_k divided out in finish_ray().
     bool ambiguous = false;             // two candidates closer than the products can tell apart: the ray goes to the exact walk
+    bool solo = false;                  // MCPT_TRI_SHARE: this lane walks the rest of its leaf itself (a near-tie needs the exact comparison)
 #endif
     int sp = 0, cur = 0, tri_i = 0, tri_end = 0;
 
@@ -269,8 +278,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                 }
             }
         } else {
-            // -------------------------------------------------------------- one triangle of the current leaf
-            if (state == ST_TRI) {
+            // -------------------------------------------------------------- triangles of the current leaves
+            // one triangle of this lane's own leaf, the sequential way
+            auto test_own_triangle = [&]() {
                 const DTri* tr = tris + tri_i;
                 tri_i++;
                 // Candidate = own box passes AND triangle test passes AND t > 0 -- a conjunction of pure tests, so the
@@ -314,25 +324,94 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                     }
 #endif
                 }
-                if (tri_i >= tri_end) {                  // leaf done: pop
-#if MCPT_POP_CULL
-                    int nxt = MCPT_FAST_EMPTY;
-                    while (sp > 0) {
-                        sp--;
-                        if (__uint_as_float((unsigned)kstack[sp * stride] << 16) <= limit_f) { nxt = stack[sp * stride]; break; }
+            };
+#if MCPT_TRI_SHARE && MCPT_LAZY_VERIFY
+            {
+                // pending pairs of this wave: lane L owns c(L) <= 4 of them; pair g = excl(L) + j is tested by lane g (g < 64)
+                int c = (state == ST_TRI && !solo) ? tri_end - tri_i : 0;
+                c = c > 4 ? 4 : c;
+                int incl = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+                const int excl = incl - c;
+                const int total = __shfl(incl, 63, 64);
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (k < c && excl + k < 64) owner_of[excl + k] = lane | (k << 8);
+                const bool work = lane < total;
+                int ow = lane, kk = 0;
+                if (work) { const int e = owner_of[lane]; ow = e & 255; kk = e >> 8; }
+                // the owner's ray, as far as the test and the rank of the distance need it
+                Ray hr;
+                hr.o = mk(__shfl(r.o.x, ow, 64), __shfl(r.o.y, ow, 64), __shfl(r.o.z, ow, 64));
+                hr.d = mk(__shfl(r.d.x, ow, 64), __shfl(r.d.y, ow, 64), __shfl(r.d.z, ow, 64));
+                const double h_rcpx = __shfl(rcp.x, ow, 64), h_best = __shfl(best.t, ow, 64);
+                const int h_found = __shfl((int)found, ow, 64);
+                const int h_tri = __shfl(tri_i, ow, 64) + kk;
+                V3 hp = mk(0, 0, 0);
+                double h_ta = __builtin_inf();          // +inf: no candidate from this pair
+                if (work) {
+                    w.tris++;
+                    if (tri_hit(tris + h_tri, hr, hp)) {
+                        const double ta = (hp.x - hr.o.x) * h_rcpx;
+                        // certainly farther than the owner's leader: not a candidate (same rule as the sequential code)
+                        if (ta > 0.0 && !(h_found && ta > h_best + h_best * 0x1p-47)) h_ta = ta;
                     }
-                    if (nxt >= 0) { cur = nxt; state = ST_INNER; }
-                    else if (nxt == MCPT_FAST_EMPTY) state = ST_IDLE;
-                    else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
-#else
-                    if (sp > 0) {
-                        sp--;
-                        const int nxt = stack[sp * stride];
-                        if (nxt >= 0) { cur = nxt; state = ST_INNER; }
-                        else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
-                    } else state = ST_IDLE;
-#endif
                 }
+                // owners collect: the smallest product among their pairs, and whether anything comes within the products' resolution
+                // of it (another pair, or the current leader) -- then the lane walks this leaf itself, with the exact comparison
+                const int done = c < 64 - excl ? c : (64 - excl > 0 ? 64 - excl : 0);      // pairs of this lane that were tested
+                double m1 = __builtin_inf(), m2 = __builtin_inf();
+                int src = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int from = (excl + k) & 63;
+                    const double tk = __shfl(h_ta, from, 64);
+                    if (k < done) {
+                        if (tk < m1) { m2 = m1; m1 = tk; src = from; }
+                        else if (tk < m2) m2 = tk;
+                    }
+                }
+                const V3 wp = mk(__shfl(hp.x, src, 64), __shfl(hp.y, src, 64), __shfl(hp.z, src, 64));
+                if (done > 0) {
+                    const bool any = m1 < __builtin_inf();
+                    const bool near_other = m2 <= m1 + m1 * 0x1p-46;                              // (inf <= inf: only when any)
+                    const bool near_leader = found && !(m1 < best.t - best.t * 0x1p-47);           // a candidate is never certainly farther
+                    if (any && (near_other || near_leader)) solo = true;                          // nothing taken, nothing skipped
+                    else {
+                        if (any) {
+                            found = true; best.leaf = tri_i + ((src - excl) & 63); best.t = m1; best.p = wp;
+                            limit = (m1 + m1 * 0x1p-47) + margin;
+                            limit_f = __double2float_ru(limit);
+                        }
+                        tri_i += done;
+                    }
+                }
+                if (__ballot(state == ST_TRI && solo)) { if (state == ST_TRI && solo) test_own_triangle(); }
+            }
+#else
+            if (state == ST_TRI) test_own_triangle();
+#endif
+            if (state == ST_TRI && tri_i >= tri_end) {   // leaf done: pop
+#if MCPT_LAZY_VERIFY
+                solo = false;
+#endif
+#if MCPT_POP_CULL
+                int nxt = MCPT_FAST_EMPTY;
+                while (sp > 0) {
+                    sp--;
+                    if (__uint_as_float((unsigned)kstack[sp * stride] << 16) <= limit_f) { nxt = stack[sp * stride]; break; }
+                }
+                if (nxt >= 0) { cur = nxt; state = ST_INNER; }
+                else if (nxt == MCPT_FAST_EMPTY) state = ST_IDLE;
+                else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
+#else
+                if (sp > 0) {
+                    sp--;
+                    const int nxt = stack[sp * stride];
+                    if (nxt >= 0) { cur = nxt; state = ST_INNER; }
+                    else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
+                } else state = ST_IDLE;
+#endif
             }
         }
     }

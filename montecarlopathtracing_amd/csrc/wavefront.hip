@@ -148,6 +148,8 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned int tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            // (one atomic per 256 paths on one word: with the word sharded 16 ways this kernel's first pass takes 6.0 instead of 6.5 ms --
+            // the counter is not its floor)
             block_base = tot ? atomicAdd(&a.counts->n_next, tot) : 0u;
         }
         __syncthreads();

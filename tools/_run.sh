@@ -1,4 +1,5 @@
-mkdir -p gpurun_out/r2h
-python -m pytest tests -q -m gpu --durations=12 > gpurun_out/r2h/tests.log 2>&1; rc=$?
-tail -32 gpurun_out/r2h/tests.log
-exit $rc
+mkdir -p gpurun_out/r2l
+for v in diagshare diagnoshare; do
+MCPT_PRINT_DIAG=1 MCPT_LIB=$PWD/montecarlopathtracing_amd/csrc/variants/libmcpt_$v.so timeout -k 10 200 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r2l/$v.json 2> gpurun_out/r2l/$v.err
+echo $v; grep "trace diag" gpurun_out/r2l/$v.err | tail -1
+done
