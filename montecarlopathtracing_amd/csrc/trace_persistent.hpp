@@ -88,6 +88,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int* __restrict__ rayflag = reinterpret_cast<int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
     int* __restrict__ owner_of = rayflag + 64;      // MCPT_TRI_SHARE: pair slot -> owning lane | (triangle offset << 8)
+    (void)owner_of;
 
     // wave-uniform supply state
     long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk
@@ -113,6 +114,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     // the fast triangle array; the candidate is verified (own box) and t_k divided out in finish_ray().
     bool ambiguous = false;             // two candidates closer than the products can tell apart: the ray goes to the exact walk
     bool solo = false;                  // MCPT_TRI_SHARE: this lane walks the rest of its leaf itself (a near-tie needs the exact comparison)
+    (void)solo;
 #endif
     int sp = 0, cur = 0, tri_i = 0, tri_end = 0;
 
