@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--tris", type=int, default=10_000_000, help="--scene synthetic: number of lattice triangles")
     ap.add_argument("--build", default="default", choices=["default", "host", "device", "device_fast"],
                     help="where the BVHs are built (mcpt_device_create_ex); device_fast: the fast walk's hierarchy on the GPU too")
+    ap.add_argument("--no-pipeline", action="store_true", help="one frame at a time (no overlap of a frame's tail with the next frame's head)")
     ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: render only one rank's tiles of an N-rank partition on this GPU")
     ap.add_argument("--sim-rank", type=int, default=0, help="with --sim-world: which rank's tiles")
     args = ap.parse_args()
@@ -193,37 +194,44 @@ def main():
         scene_dir = write_scene_dir(args.scene, args.width, args.height)
         scene = M.Scene(scene_dir, args.scene)
         dev = M.Device(scene, local_rank, build=build_mode)
-    rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev, stage_on_cpu=share_gpu)
+    # A renderer of a sequence of frames: two frames in flight (the device's two frame slots, two streams, two frame tensors), so
+    # the latency-bound tail of frame i overlaps the head of frame i+1, and no frame waits for its statistics (they stay on the
+    # device until the timed region is over).  --no-pipeline: one frame at a time, statistics read back after every frame.
+    pipeline = not args.no_pipeline and not share_gpu
     if args.sim_world > 1:          # one rank's share of an N-way partition, no communication
-        class _Sim:
-            def __init__(self):
-                import torch as _t
-                self.frame = _t.zeros((dev.height * dev.width, 3), dtype=_t.float64, device=tdev)
-            def render(self, spp, seed=0, stats=None, flags=0):
-                dev.render_device(self.frame.data_ptr(), spp, seed, args.sim_rank, args.sim_world, 0, 0, flags, stats,
-                                  torch.cuda.current_stream(tdev).cuda_stream)
-                return self.frame
-        rr = _Sim()
+        rr = DistributedRenderer(scene, dev, args.sim_rank, args.sim_world, torch_device=tdev, pipeline=pipeline, gather=False)
+    else:
+        rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev, stage_on_cpu=share_gpu, pipeline=pipeline)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if pipeline:                    # both frame slots get their workspace (83 GB each for the headline frame) outside the timed region
+        for _ in range(2):
+            rr.render(args.spp, args.seed)
     for _ in range(args.warmup):
         rr.render(args.spp, args.seed)
     sync()
+    if pipeline:
+        dev.collect_stats()         # discard what the untimed frames left
     stats = M.Stats()
     tot = {"rays": 0, "node_visits": 0, "tri_tests": 0, "samples": 0, "ms_trace": 0.0, "launches": 0, "rays_primary": 0,
            "rays_shadow": 0, "rays_bounce": 0, "dom_rays": 0, "dom_node_visits": 0, "dom_tri_tests": 0}
     t0 = time.perf_counter()
     frame = None
     for _ in range(args.steps):
-        frame = rr.render(args.spp, args.seed, stats=stats)
-        for k in tot:
-            tot[k] += getattr(stats, k)
+        frame = rr.render(args.spp, args.seed, stats=None if pipeline else stats)
+        if not pipeline:
+            for k in tot:
+                tot[k] += getattr(stats, k)
     sync()
     elapsed = time.perf_counter() - t0
+    if pipeline:                    # the events were recorded inside the timed region; they are read here, after it
+        dev.collect_stats(stats)
+        for k in tot:
+            tot[k] = getattr(stats, k)
 
     red_dev = torch.device("cpu") if share_gpu else tdev
     vals = torch.tensor([elapsed] + [float(tot[k]) for k in ("rays", "node_visits", "tri_tests", "samples", "launches")] + [tot["ms_trace"]],
@@ -275,7 +283,8 @@ def main():
             if scene_dir is not None else "synthetic lattice scene, %d triangles, generator seed 42 (montecarlopathtracing_amd/synthetic.py)" % scene.info.num_faces,
             "config": {"workload": "%s %dx%d SPP=%d" % (args.scene, args.width, args.height, args.spp), "seed": args.seed,
                        "partition": "32x8-pixel tiles round-robin over ranks, RCCL gather to rank 0",
-                       "primary_rays": "traced once per pixel (identical for every sample: the reference has no jitter)"},
+                       "primary_rays": "traced once per pixel (identical for every sample: the reference has no jitter)",
+                       "frames_in_flight": 2 if pipeline else 1},
             "rays_per_frame": rays / steps, "samples_per_frame": samples / steps,
             "nodes_per_ray": nodes / max(1.0, rays), "tris_per_ray": tris / max(1.0, rays),
             "roofline": {"bound": "hbm", "kernel": "k_wf_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

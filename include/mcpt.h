@@ -81,6 +81,14 @@ typedef struct {
 #define MCPT_RENDER_DEFAULT      0
 #define MCPT_RENDER_MEGAKERNEL   2   /* one lane per camera sample, whole path in one kernel, reference-shaped walk
                                        (the first implementation; kept for A/B runs).  Default: wavefront pipeline. */
+/* A renderer that produces a SEQUENCE of frames (mcpt_render_device only):
+ *   MCPT_RENDER_KEEP_STATS  the frame's statistics stay on the device (counters accumulate, event pairs are recorded, nothing is
+ *                           read back) until mcpt_device_collect_stats: the call returns without waiting for the frame.
+ *   MCPT_RENDER_PIPELINE    consecutive frames use the device's two frame slots (path state, radiance, counters) in turn.  Called
+ *                           on alternating streams, the latency-bound tail of frame i (the last long paths, the fold) then overlaps
+ *                           the head of frame i+1.  The caller gives every frame in flight its own d_img. */
+#define MCPT_RENDER_KEEP_STATS   4
+#define MCPT_RENDER_PIPELINE     8
 
 /* ---- general ---- */
 int         mcpt_version(void);
@@ -179,6 +187,9 @@ int  mcpt_trace_closest_device(mcpt_device*, const double* d_rays, int64_t n, in
  * rank does not own are left untouched.  stats may be NULL. */
 int  mcpt_render(mcpt_device*, const mcpt_render_params*, double* img, mcpt_stats* stats);
 int  mcpt_render_device(mcpt_device*, const mcpt_render_params*, double* d_img, mcpt_stats* stats, void* stream);
+/* statistics of all MCPT_RENDER_KEEP_STATS frames since the last call (waits for them; counts summed, ms_trace = sum over
+ * k_wf_trace launches, ms_total = sum of the frames' own durations -- pipelined frames overlap) */
+int  mcpt_device_collect_stats(mcpt_device*, mcpt_stats* stats);
 /* radiance of single camera samples: pix[n] = row*W+col, k[n] = sample index -> rgb[n*3] (test seam, host pointers) */
 int  mcpt_sample_radiance(mcpt_device*, uint64_t seed, const int32_t* pix, const int32_t* k, int64_t n, double* rgb);
 /* number of pixels owned by (rank, world) under the tile partition, and their indices (row*W+col, ascending) */

@@ -73,7 +73,7 @@ EXPORTS = [
     "mcpt_device_create", "mcpt_device_create_ex", "mcpt_device_get_bvh_nodes", "mcpt_device_get_leaf_order", "mcpt_device_free",
     "mcpt_device_set_trace_mode",
     "mcpt_trace_closest", "mcpt_trace_closest_device",
-    "mcpt_render", "mcpt_render_device", "mcpt_sample_radiance", "mcpt_owned_pixels",
+    "mcpt_render", "mcpt_render_device", "mcpt_device_collect_stats", "mcpt_sample_radiance", "mcpt_owned_pixels",
     "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_png_encode_deflate", "mcpt_write_png_deflate", "mcpt_write_pfm",
     "mcpt_checkpoint_save", "mcpt_checkpoint_load", "mcpt_decode_jpeg",
     "mcpt_multi_create", "mcpt_multi_num_devices", "mcpt_multi_render", "mcpt_multi_render_device", "mcpt_multi_free",
@@ -129,6 +129,7 @@ def lib():
     L.mcpt_trace_closest_device.argtypes = [P, P, C.c_int64, P, P, P, P, P]
     L.mcpt_render.argtypes = [P, C.POINTER(RenderParams), D, C.POINTER(Stats)]
     L.mcpt_render_device.argtypes = [P, C.POINTER(RenderParams), P, C.POINTER(Stats), P]
+    L.mcpt_device_collect_stats.argtypes = [P, C.POINTER(Stats)]
     L.mcpt_sample_radiance.argtypes = [P, C.c_uint64, I32, I32, C.c_int64, D]
     L.mcpt_owned_pixels.restype = C.c_int64
     L.mcpt_owned_pixels.argtypes = [P, C.POINTER(RenderParams), I32]

@@ -10,6 +10,7 @@ from ._lib import McptError, RenderParams, RenderSceneOptions, SceneDesc, SceneI
 
 TRACE_FAST, TRACE_REFERENCE = 0, 1
 RENDER_DEFAULT, RENDER_MEGAKERNEL = 0, 2
+RENDER_KEEP_STATS, RENDER_PIPELINE = 4, 8
 LOAD_STANDARD_OBJ, LOAD_MTLLIB, LOAD_MORTON_BOUNDS = 1, 2, 4
 OUT_PNG_DEFLATE, OUT_PFM = 1, 2
 BUILD_HOST, BUILD_DEVICE, BUILD_DEVICE_FAST = 0, 1, 2
@@ -221,6 +222,12 @@ class Device:
         rp = RenderParams(spp, seed, rank, world, tile_w, tile_h, flags)
         check(lib().mcpt_render_device(self._h, C.byref(rp), C.c_void_p(d_img_ptr), C.byref(stats) if stats is not None else None,
                                        C.c_void_p(stream) if stream else None))
+
+    def collect_stats(self, stats=None):
+        """statistics of every RENDER_KEEP_STATS frame since the last call (waits for those frames)"""
+        stats = stats if stats is not None else Stats()
+        check(lib().mcpt_device_collect_stats(self._h, C.byref(stats)))
+        return stats
 
     def sample_radiance(self, seed, pix, k):
         pix = np.ascontiguousarray(pix, dtype=np.int32)

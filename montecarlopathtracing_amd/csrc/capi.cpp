@@ -98,23 +98,38 @@ struct mcpt_device {
     int width = 0, height = 0;
     double* dirs = nullptr;                // W*H*3 primary directions
     bool dirs_ready = false;
-    DCounters* ctr = nullptr;
     // render workspace
     int32_t* pixels = nullptr; int64_t n_pixels = 0; int part_key[4] = {-1, -1, -1, -1};
-    PrimaryHit* hits = nullptr; int64_t hits_cap = 0;
-    double* rad = nullptr; size_t rad_cap = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t look_stream = nullptr;     // the host's looks at a path count travel here, so that they wait for the logic pass that wrote
+    hipEvent_t look_ev = nullptr;          // the count and for nothing enqueued after it (the finishing kernel above all)
     size_t sample_budget_bytes = size_t(4) << 30;   // megakernel path: radiance staging buffer per chunk
-    // wavefront workspace
-    size_t wf_budget_bytes = 0;                     // path state + rays; 0 = half of the free HBM (MCPT_WORKSPACE_GB overrides)
-    size_t wf_auto_budget = 0;                      // that half, asked for once (hipMemGetInfo costs a few hundred microseconds)
-    void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
-    int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
-    PrimarySurface* surf = nullptr; int64_t surf_cap = 0;   // first-vertex record per hit pixel of the chunk
-    WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
+    size_t wf_budget_bytes = 0;                     // path state + rays per frame slot; 0 = a share of the free HBM (MCPT_WORKSPACE_GB overrides)
+    size_t wf_auto_budget = 0;                      // that share, asked for once (hipMemGetInfo costs a few hundred microseconds)
+    // Everything a frame in flight owns.  Two slots: with MCPT_RENDER_PIPELINE consecutive frames alternate between them, so the
+    // latency-bound tail of one frame (the finishing kernel's last long paths, the fold) overlaps the head of the next on another stream.
+    struct FrameSlot {
+        PrimaryHit* hits = nullptr; int64_t hits_cap = 0;
+        double* rad = nullptr; size_t rad_cap = 0;
+        void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
+        int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
+        PrimarySurface* surf = nullptr; int64_t surf_cap = 0;   // first-vertex record per hit pixel of the chunk
+        WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
+        TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
+        long long* slow_list = nullptr;
+        DCounters* ctr = nullptr;
+        hipEvent_t done = nullptr;                      // recorded after the slot's last kernel of a frame
+        bool used = false;
+        bool keeping = false;                           // ctr holds kept statistics of earlier frames (must not be cleared)
+    } slot[2];
+    int next_slot = 0;
+    bool pipelined = false;                         // set by the first MCPT_RENDER_PIPELINE frame (sizes the workspace budget)
+    // statistics kept on the device side until mcpt_device_collect_stats (MCPT_RENDER_KEEP_STATS)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // start/stop pairs around trace launches
-    TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
-    long long* slow_list = nullptr;
+    size_t ev_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> frame_ev;  // start/stop of every kept frame
+    size_t frame_ev_used = 0;
+    uint64_t kept_samples = 0, kept_primary = 0; int kept_launches = 0;
     unsigned int slow_cap = 1u << 20;
     LaunchCfg cfg;                                  // this GPU's resident grids and knobs
     long long finish_threshold = 500000;            // paths left at which the finishing pass takes over (MCPT_FINISH_PATHS; sweep: flat from 2e5 to 1e6)
@@ -428,10 +443,18 @@ void mcpt_device_free(mcpt_device* d)
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
     void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes, d->d_order,
-                    d->dirs, d->ctr, d->pixels, d->hits, d->rad, d->wf_ws, d->hit_slots, d->surf, d->wf_counts, d->queue, d->slow_list};
+                    d->dirs, d->pixels};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& f : d->slot) {
+        void* q[] = {f.hits, f.rad, f.wf_ws, f.hit_slots, f.surf, f.wf_counts, f.queue, f.slow_list, f.ctr};
+        for (void* p : q) if (p) (void)hipFree(p);
+        if (f.done) (void)hipEventDestroy(f.done);
+    }
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pr : d->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : d->frame_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (d->look_stream) (void)hipStreamDestroy(d->look_stream);
+    if (d->look_ev) (void)hipEventDestroy(d->look_ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -456,6 +479,8 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     d->ordinal = ordinal;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipStreamCreateWithFlags(&d->look_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d->look_ev, hipEventDisableTiming));
 
     const int t = int(s.faces.size());
     const mcpt_bvh_info bi = bvh_shape(t);
@@ -627,12 +652,15 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         (void)hipFree(d_slots);
         if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("fast triangle gather: ") + hipGetErrorString(e));
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->ctr), sizeof(DCounters)));
-    HIP_TRY(hipMemset(d->ctr, 0, sizeof(DCounters)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->wf_counts), sizeof(WfCounts) * MCPT_WF_COUNT_SLOTS));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->queue), sizeof(TraceQueue)));
     if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->slow_list), size_t(d->slow_cap) * sizeof(long long)));
+    for (auto& f : d->slot) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.ctr), sizeof(DCounters)));
+        HIP_TRY(hipMemset(f.ctr, 0, sizeof(DCounters)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.wf_counts), sizeof(WfCounts) * MCPT_WF_COUNT_SLOTS));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.queue), sizeof(TraceQueue)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.slow_list), size_t(d->slow_cap) * sizeof(long long)));
+        HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    }
     if (const char* e = std::getenv("MCPT_FINISH_PATHS")) d->finish_threshold = std::atoll(e);
     init_launch_cfg(d->cfg);
     if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
@@ -739,7 +767,7 @@ int mcpt_trace_closest_device(mcpt_device* d, const double* d_rays, int64_t n, i
     if (!d || (n > 0 && !d_rays) || n < 0) return fail(MCPT_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(d->ordinal));
     if (!d_face || !d_t || !d_p) return fail(MCPT_ERR_ARG, "d_face, d_t and d_p are required by the device form");
-    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->queue, d->slow_list, d->slow_cap,
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->slot[0].ctr, d->slot[0].queue, d->slot[0].slow_list, d->slow_cap,
                          static_cast<hipStream_t>(stream), d->cfg);
     HIP_TRY(hipGetLastError());
     return MCPT_OK;
@@ -761,9 +789,9 @@ int mcpt_trace_closest(mcpt_device* d, const double* rays, int64_t n, int32_t* f
     TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_p), size_t(n) * 3 * sizeof(double)));
     TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_pn), size_t(n) * 3 * sizeof(double)));
     TRY_OR_CLEAN(hipMemcpyAsync(d_rays, rays, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice, d->stream));
-    TRY_OR_CLEAN(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), d->stream));
+    TRY_OR_CLEAN(hipMemsetAsync(d->slot[0].ctr, 0, sizeof(DCounters), d->stream));
     TRY_OR_CLEAN(hipEventRecord(d->ev[0], d->stream));
-    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->ctr, d->queue, d->slow_list, d->slow_cap, d->stream, d->cfg);
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->slot[0].ctr, d->slot[0].queue, d->slot[0].slow_list, d->slow_cap, d->stream, d->cfg);
     TRY_OR_CLEAN(hipGetLastError());
     TRY_OR_CLEAN(hipEventRecord(d->ev[1], d->stream));
     if (face) TRY_OR_CLEAN(hipMemcpyAsync(face, d_face, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
@@ -771,7 +799,7 @@ int mcpt_trace_closest(mcpt_device* d, const double* rays, int64_t n, int32_t* f
     if (p) TRY_OR_CLEAN(hipMemcpyAsync(p, d_p, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, d->stream));
     if (pn) TRY_OR_CLEAN(hipMemcpyAsync(pn, d_pn, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, d->stream));
     DCounters c{};
-    TRY_OR_CLEAN(hipMemcpyAsync(&c, d->ctr, sizeof c, hipMemcpyDeviceToHost, d->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(&c, d->slot[0].ctr, sizeof c, hipMemcpyDeviceToHost, d->stream));
     TRY_OR_CLEAN(hipStreamSynchronize(d->stream));
     if (stats) {
         counters_to_stats(c, stats);
@@ -794,7 +822,10 @@ static int prepare_partition(mcpt_device* d, const mcpt_render_params* p, hipStr
     if (std::memcmp(key, d->part_key, sizeof key) == 0 && d->pixels) return MCPT_OK;
     std::vector<int32_t> v;
     owned_pixel_list(d->width, d->height, tw, th, rank, world, v);
-    if (d->pixels) { (void)hipFree(d->pixels); d->pixels = nullptr; }
+    if (d->pixels) {
+        HIP_TRY(hipDeviceSynchronize());       // a frame of the previous partition may still be in flight (MCPT_RENDER_KEEP_STATS / PIPELINE)
+        (void)hipFree(d->pixels); d->pixels = nullptr;
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->pixels), std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
     if (!v.empty()) {
         HIP_TRY(hipMemcpyAsync(d->pixels, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -807,7 +838,7 @@ static int prepare_partition(mcpt_device* d, const mcpt_render_params* p, hipStr
 
 // megakernel path: one lane per camera sample, the whole path in one kernel (kept for A/B runs and as a second
 // implementation the wavefront path is checked against)
-static int render_megakernel(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, hipStream_t st,
+static int render_megakernel(mcpt_device* d, mcpt_device::FrameSlot& f, const mcpt_render_params* p, double* d_img, bool timed, hipStream_t st,
                              double& ms_trace, int& launches)
 {
     const int64_t npx = d->n_pixels;
@@ -815,18 +846,18 @@ static int render_megakernel(mcpt_device* d, const mcpt_render_params* p, double
     const size_t per_pixel = size_t(spp) * 3 * sizeof(double);
     int64_t chunk = int64_t(std::max<size_t>(d->sample_budget_bytes / per_pixel, 64));
     chunk = std::min<int64_t>(chunk, npx);
-    if (d->rad_cap < size_t(chunk) * per_pixel) {
-        if (d->rad) (void)hipFree(d->rad);
-        d->rad = nullptr; d->rad_cap = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->rad), size_t(chunk) * per_pixel));
-        d->rad_cap = size_t(chunk) * per_pixel;
+    if (f.rad_cap < size_t(chunk) * per_pixel) {
+        if (f.rad) (void)hipFree(f.rad);
+        f.rad = nullptr; f.rad_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.rad), size_t(chunk) * per_pixel));
+        f.rad_cap = size_t(chunk) * per_pixel;
     }
     for (int64_t first = 0; first < npx; first += chunk) {
         const int n_slots = int(std::min<int64_t>(chunk, npx - first));
-        if (stats) HIP_TRY(hipEventRecord(d->ev[2], st));
-        launch_shade_samples(d->ds, p->seed, d->dirs, d->pixels, d->hits, int(first), n_slots, spp, d->rad, d->ctr, st);
+        if (timed) HIP_TRY(hipEventRecord(d->ev[2], st));
+        launch_shade_samples(d->ds, p->seed, d->dirs, d->pixels, f.hits, int(first), n_slots, spp, f.rad, f.ctr, st);
         HIP_TRY(hipGetLastError());
-        if (stats) {
+        if (timed) {
             HIP_TRY(hipEventRecord(d->ev[3], st));
             HIP_TRY(hipEventSynchronize(d->ev[3]));
             float ms = 0;
@@ -834,14 +865,16 @@ static int render_megakernel(mcpt_device* d, const mcpt_render_params* p, double
             ms_trace += ms;
         }
         launches++;
-        launch_fold_samples(d->rad, d->pixels, d->hits, int(first), n_slots, spp, d_img, st);
+        launch_fold_samples(f.rad, d->pixels, f.hits, int(first), n_slots, spp, d_img, st);
         HIP_TRY(hipGetLastError());
     }
     return MCPT_OK;
 }
 
-// wavefront path (wavefront.hpp): per chunk, lockstep iterations of logic + trace over compacted path state in HBM
-static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, hipStream_t st,
+// wavefront path (wavefront.hpp): per chunk, lockstep iterations of logic + trace over compacted path state in HBM.
+// timed: event pairs around the trace launches, summed here (one stream synchronisation at the end); keep: the pairs are recorded
+// and left in d->ev_pool for mcpt_device_collect_stats -- the frame ends without the host waiting for it.
+static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcpt_render_params* p, double* d_img, bool timed, bool keep, hipStream_t st,
                             double& ms_trace, int& launches)
 {
     const int64_t npx = d->n_pixels;
@@ -851,14 +884,17 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
     const size_t bpp = wf_bytes_per_path(nl);
     // chunk: as many pixels as the workspace budget holds paths for (every pixel may hit)
     const size_t overhead = 64 * 1024;
-    // Fewer, larger chunks are cheaper (every chunk ends in a tail of small launches): by default a chunk may use half of
-    // the HBM that is free, which holds a whole 1280x720 SPP-256 frame (83 GB) on a 288-GB device.
+    // Fewer, larger chunks are cheaper (every chunk ends in a tail of small launches): by default a frame slot may use half of
+    // the HBM that is free (a third when two frames are pipelined), which holds a whole 1280x720 SPP-256 frame (83 GB) on a
+    // 288-GB device.
     size_t budget = d->wf_budget_bytes;
     if (!budget) {
         if (!d->wf_auto_budget) {
             size_t free_b = 0, total_b = 0;
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            d->wf_auto_budget = std::max<size_t>((free_b + d->wf_ws_bytes + d->rad_cap) / 2, size_t(1) << 30);
+            size_t mine = 0;
+            for (const auto& q : d->slot) mine += q.wf_ws_bytes + q.rad_cap;
+            d->wf_auto_budget = std::max<size_t>((free_b + mine) / (d->pipelined ? 3 : 2), size_t(1) << 30);
         }
         budget = d->wf_auto_budget;
     }
@@ -869,98 +905,111 @@ static int render_wavefront(mcpt_device* d, const mcpt_render_params* p, double*
     chunk_slots = std::min<int64_t>(chunk_slots, npx);
     cap = chunk_slots * spp;
     const size_t ws_need = size_t(cap) * bpp + overhead;
-    if (d->wf_ws_bytes < ws_need) {
-        if (d->wf_ws) (void)hipFree(d->wf_ws);
-        d->wf_ws = nullptr; d->wf_ws_bytes = 0;
-        HIP_TRY(hipMalloc(&d->wf_ws, ws_need));
-        d->wf_ws_bytes = ws_need;
+    if (f.wf_ws_bytes < ws_need) {
+        if (f.wf_ws) (void)hipFree(f.wf_ws);
+        f.wf_ws = nullptr; f.wf_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&f.wf_ws, ws_need));
+        f.wf_ws_bytes = ws_need;
     }
     const size_t rad_need = size_t(cap) * 3 * sizeof(double);
-    if (d->rad_cap < rad_need) {
-        if (d->rad) (void)hipFree(d->rad);
-        d->rad = nullptr; d->rad_cap = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->rad), rad_need));
-        d->rad_cap = rad_need;
+    if (f.rad_cap < rad_need) {
+        if (f.rad) (void)hipFree(f.rad);
+        f.rad = nullptr; f.rad_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.rad), rad_need));
+        f.rad_cap = rad_need;
     }
-    int rc = grow(&d->hit_slots, &d->hit_slots_cap, chunk_slots);
+    int rc = grow(&f.hit_slots, &f.hit_slots_cap, chunk_slots);
     if (rc) return rc;
-    if ((rc = grow(&d->surf, &d->surf_cap, chunk_slots))) return rc;
+    if ((rc = grow(&f.surf, &f.surf_cap, chunk_slots))) return rc;
     WfArgs a{};
     WfState A, B;
-    if (!wf_carve(d->wf_ws, d->wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
-    a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = d->hit_slots; a.surf = d->surf; a.hits = d->hits;
-    a.dirs = d->dirs; a.rad = d->rad; a.counts = d->wf_counts; a.ctr = d->ctr; a.tris = d->tris;
+    if (!wf_carve(f.wf_ws, f.wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
+    a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = f.hit_slots; a.surf = f.surf; a.hits = f.hits;
+    a.dirs = d->dirs; a.rad = f.rad; a.counts = f.wf_counts; a.ctr = f.ctr; a.tris = d->tris;
     a.finish_below = fast ? unsigned(std::min<long long>(std::max<long long>(d->finish_threshold, 0), 1ll << 30)) : 0u;
     // Iterations are enqueued without waiting for their counts: every kernel reads its input count from the device slot the
     // previous one wrote.  The host looks at a count only every few iterations (to stop, and to size the next grids).
-    size_t ev_used = 0;
+    const size_t ev_first = d->ev_used;
     auto next_pair = [&](std::pair<hipEvent_t, hipEvent_t>*& out) -> int {
-        if (ev_used == d->ev_pool.size()) {
+        if (d->ev_used == d->ev_pool.size()) {
             hipEvent_t e0, e1;
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
             d->ev_pool.emplace_back(e0, e1);
         }
-        out = &d->ev_pool[ev_used++];
+        out = &d->ev_pool[d->ev_used++];
         return MCPT_OK;
     };
     const int kSyncEvery = 4;
     for (int64_t first = 0; first < npx; first += chunk_slots) {
         const int n_slots = int(std::min<int64_t>(chunk_slots, npx - first));
-        HIP_TRY(hipMemsetAsync(d->wf_counts, 0, sizeof(WfCounts) * MCPT_WF_COUNT_SLOTS, st));
-        launch_hit_slots(d->hits, int(first), n_slots, d->hit_slots, &d->wf_counts[0].n_next, st);
+        HIP_TRY(hipMemsetAsync(f.wf_counts, 0, sizeof(WfCounts) * MCPT_WF_COUNT_SLOTS, st));
+        launch_hit_slots(f.hits, int(first), n_slots, f.hit_slots, &f.wf_counts[0].n_next, st);
         HIP_TRY(hipGetLastError());
         long long n_upper = (long long)n_slots * spp;        // upper bound of the live paths, refined at every look
         double n_grid = double(n_upper);                     // grid-sizing estimate between looks (kernels stride, any grid is correct)
         a.first_slot = int(first);
         a.in = A; a.out = B;
-        a.counts_in = &d->wf_counts[0];
-        launch_primary_surface(d->ds, a, d->surf, n_slots, st);      // what the samples of a pixel share at their first vertex
+        a.counts_in = &f.wf_counts[0];
+        launch_primary_surface(d->ds, a, f.surf, n_slots, st);      // what the samples of a pixel share at their first vertex
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < MCPT_MAX_DEPTH && n_upper > 0; depth++) {
             a.depth = depth;
-            a.counts_in = &d->wf_counts[depth]; a.count_mul = depth == 0 ? unsigned(spp) : 1u;
-            a.counts = &d->wf_counts[depth + 1];
+            a.counts_in = &f.wf_counts[depth]; a.count_mul = depth == 0 ? unsigned(spp) : 1u;
+            a.counts = &f.wf_counts[depth + 1];
             const long long n_launch = std::max<long long>(1, (long long)n_grid);
             launch_wf_logic(d->ds, a, n_launch, depth == 0, st, d->cfg);
             HIP_TRY(hipGetLastError());
-            if (a.finish_below) {
+            // The host looks at this pass's count every few iterations, and at every iteration once the hand-over to the finishing
+            // kernel is near.  The look waits for this logic pass only (event + side stream): when it finds the hand-over, the
+            // finishing kernel is launched and the call returns while it runs -- the next frame's head can overlap it.
+            const bool look = (depth + 1) % kSyncEvery == 0 || (a.finish_below && n_grid * 0.6 <= 6.0 * double(a.finish_below));
+            if (look) {
+                unsigned int n_now = 0;
+                HIP_TRY(hipEventRecord(d->look_ev, st));
+                HIP_TRY(hipStreamWaitEvent(d->look_stream, d->look_ev, 0));
+                HIP_TRY(hipMemcpyAsync(&n_now, &f.wf_counts[depth + 1].n_next, sizeof n_now, hipMemcpyDeviceToHost, d->look_stream));
+                HIP_TRY(hipStreamSynchronize(d->look_stream));
+                if (n_now <= a.finish_below) {
+                    if (n_now > 0) { launch_wf_finish(d->ds, a, (long long)n_now, st, d->cfg); HIP_TRY(hipGetLastError()); }
+                    n_upper = 0;
+                    break;
+                }
+                n_upper = n_now;
+                n_grid = double(n_now);
+            } else if (a.finish_below) {
                 // few paths left (decided on the device from this pass's count): one lane per path runs them to the end
                 launch_wf_finish(d->ds, a, std::min<long long>(n_launch, (long long)a.finish_below), st, d->cfg);
                 HIP_TRY(hipGetLastError());
             }
+            const long long n_trace = look ? (long long)n_grid : n_launch;
             std::pair<hipEvent_t, hipEvent_t>* pr = nullptr;
-            if (stats) { if ((rc = next_pair(pr))) return rc; HIP_TRY(hipEventRecord(pr->first, st)); }
-            launch_wf_trace(d->ds, a, n_launch, fast, d->queue, d->slow_list, d->slow_cap, st, d->cfg);
+            if (timed || keep) { if ((rc = next_pair(pr))) return rc; HIP_TRY(hipEventRecord(pr->first, st)); }
+            launch_wf_trace(d->ds, a, n_trace, fast, f.queue, f.slow_list, d->slow_cap, st, d->cfg);
             HIP_TRY(hipGetLastError());
-            if (stats) HIP_TRY(hipEventRecord(pr->second, st));
+            if (timed || keep) HIP_TRY(hipEventRecord(pr->second, st));
             launches++;
             std::swap(a.in, a.out);
-            if ((depth + 1) % kSyncEvery == 0) {
-                unsigned int n_now = 0;
-                HIP_TRY(hipMemcpyAsync(&n_now, &d->wf_counts[depth + 1].n_next, sizeof n_now, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                n_upper = n_now <= a.finish_below ? 0 : n_now;
-                n_grid = double(n_now);
-            } else n_grid *= 0.75;   // paths die at >= 40 % per bounce (Russian roulette 0.6)
+            if (!look) n_grid *= 0.75;   // paths die at >= 40 % per bounce (Russian roulette 0.6)
         }
         // paths still alive at the depth cap cannot exist: logic(MAX_DEPTH-1) emits no bounce ray; a last logic pass resolves them
         if (n_upper > 0) {
             a.depth = MCPT_MAX_DEPTH;
-            a.counts_in = &d->wf_counts[MCPT_MAX_DEPTH]; a.count_mul = 1u; a.counts = &d->wf_counts[MCPT_MAX_DEPTH + 1];
+            a.counts_in = &f.wf_counts[MCPT_MAX_DEPTH]; a.count_mul = 1u; a.counts = &f.wf_counts[MCPT_MAX_DEPTH + 1];
             launch_wf_logic(d->ds, a, n_upper, false, st, d->cfg);
             HIP_TRY(hipGetLastError());
         }
-        launch_fold_samples(d->rad, d->pixels, d->hits, int(first), n_slots, spp, d_img, st);
+        launch_fold_samples(f.rad, d->pixels, f.hits, int(first), n_slots, spp, d_img, st);
         HIP_TRY(hipGetLastError());
     }
-    if (stats) {
+    if (timed && !keep) {
         HIP_TRY(hipStreamSynchronize(st));
-        for (size_t i = 0; i < ev_used; i++) {
+        for (size_t i = ev_first; i < d->ev_used; i++) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, d->ev_pool[i].first, d->ev_pool[i].second));
             ms_trace += ms;
         }
+        d->ev_used = ev_first;
     }
     return MCPT_OK;
 }
@@ -971,26 +1020,53 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
     HIP_TRY(hipSetDevice(d->ordinal));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (stats) std::memset(stats, 0, sizeof *stats);
+    const bool keep = (p->flags & MCPT_RENDER_KEEP_STATS) != 0 && !(p->flags & MCPT_RENDER_MEGAKERNEL);
+    const bool timed = stats != nullptr && !keep;
+    // frame slot: consecutive pipelined frames alternate; a slot's previous frame (possibly on another stream) must be over
+    if ((p->flags & MCPT_RENDER_PIPELINE) && !d->pipelined) {
+        HIP_TRY(hipDeviceSynchronize());
+        d->pipelined = true; d->wf_auto_budget = 0;                  // the budget now has to hold two frames
+        for (auto& q : d->slot) { if (q.wf_ws) (void)hipFree(q.wf_ws); q.wf_ws = nullptr; q.wf_ws_bytes = 0; }
+    }
+    const int si = (p->flags & MCPT_RENDER_PIPELINE) ? (d->next_slot ^= 1) : 0;
+    mcpt_device::FrameSlot& f = d->slot[si];
+    if (f.used) HIP_TRY(hipStreamWaitEvent(st, f.done, 0));
     int rc = ensure_dirs(d, st);
     if (rc) return rc;
     rc = prepare_partition(d, p, st);
     if (rc) return rc;
     const int64_t npx = d->n_pixels;
     if (npx == 0) return MCPT_OK;
-    if ((rc = grow(&d->hits, &d->hits_cap, npx))) return rc;
-    HIP_TRY(hipMemsetAsync(d->ctr, 0, sizeof(DCounters), st));
-    HIP_TRY(hipEventRecord(d->ev[0], st));
-    launch_primary_hits(d->ds, d->trace_mode == MCPT_TRACE_FAST, d->dirs, d->pixels, int(npx), d->hits, d->ctr, d->queue, d->slow_list, d->slow_cap, st, d->cfg);
+    if ((rc = grow(&f.hits, &f.hits_cap, npx))) return rc;
+    if (!keep || !f.keeping) HIP_TRY(hipMemsetAsync(f.ctr, 0, sizeof(DCounters), st));    // kept statistics accumulate until they are collected
+    f.keeping = keep;
+    std::pair<hipEvent_t, hipEvent_t>* fe = nullptr;
+    if (keep) {
+        if (d->frame_ev_used == d->frame_ev.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            d->frame_ev.emplace_back(e0, e1);
+        }
+        fe = &d->frame_ev[d->frame_ev_used++];
+        HIP_TRY(hipEventRecord(fe->first, st));
+    } else HIP_TRY(hipEventRecord(d->ev[0], st));
+    launch_primary_hits(d->ds, d->trace_mode == MCPT_TRACE_FAST, d->dirs, d->pixels, int(npx), f.hits, f.ctr, f.queue, f.slow_list, d->slow_cap, st, d->cfg);
     HIP_TRY(hipGetLastError());
     double ms_trace = 0;
     int launches = 0;
-    if (p->flags & MCPT_RENDER_MEGAKERNEL) rc = render_megakernel(d, p, d_img, stats, st, ms_trace, launches);
-    else rc = render_wavefront(d, p, d_img, stats, st, ms_trace, launches);
+    if (p->flags & MCPT_RENDER_MEGAKERNEL) rc = render_megakernel(d, f, p, d_img, timed, st, ms_trace, launches);
+    else rc = render_wavefront(d, f, p, d_img, timed, keep, st, ms_trace, launches);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(d->ev[1], st));
-    if (stats) {
+    if (keep) {
+        HIP_TRY(hipEventRecord(fe->second, st));
+        d->kept_samples += uint64_t(npx) * uint64_t(p->spp); d->kept_primary += uint64_t(npx); d->kept_launches += launches;
+    } else HIP_TRY(hipEventRecord(d->ev[1], st));
+    HIP_TRY(hipEventRecord(f.done, st));
+    f.used = true;
+    if (timed) {
         DCounters c{};
-        HIP_TRY(hipMemcpyAsync(&c, d->ctr, sizeof c, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&c, f.ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         counters_to_stats(c, stats);
         float ms = 0;
@@ -999,6 +1075,41 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
         stats->samples = uint64_t(npx) * uint64_t(p->spp);      // camera samples covered (a primary miss is a finished sample)
         stats->rays_primary = uint64_t(npx);
     }
+    return MCPT_OK;
+}
+
+// Statistics of every MCPT_RENDER_KEEP_STATS frame since the last call: waits for those frames, sums the device counters of both
+// frame slots, the event pairs around every k_wf_trace launch (ms_trace) and around every frame (ms_total = sum of frame times;
+// pipelined frames overlap, so this can exceed the wall time), then starts over.
+int mcpt_device_collect_stats(mcpt_device* d, mcpt_stats* stats)
+{
+    if (!d || !stats) return fail(MCPT_ERR_ARG, "null argument");
+    std::memset(stats, 0, sizeof *stats);
+    HIP_TRY(hipSetDevice(d->ordinal));
+    HIP_TRY(hipDeviceSynchronize());
+    DCounters sum{};
+    for (auto& f : d->slot) {
+        DCounters c{};
+        HIP_TRY(hipMemcpy(&c, f.ctr, sizeof c, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(f.ctr, 0, sizeof(DCounters)));
+        unsigned long long* a = reinterpret_cast<unsigned long long*>(&sum);
+        const unsigned long long* b = reinterpret_cast<const unsigned long long*>(&c);
+        for (size_t i = 0; i < sizeof(DCounters) / sizeof(unsigned long long); i++) a[i] += b[i];
+        sum.max_depth = std::max(sum.max_depth - c.max_depth, c.max_depth);      // a maximum, not a sum
+    }
+    counters_to_stats(sum, stats);
+    for (size_t i = 0; i < d->ev_used; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev_pool[i].first, d->ev_pool[i].second));
+        stats->ms_trace += ms;
+    }
+    for (size_t i = 0; i < d->frame_ev_used; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d->frame_ev[i].first, d->frame_ev[i].second));
+        stats->ms_total += ms;
+    }
+    stats->launches = d->kept_launches; stats->samples = d->kept_samples; stats->rays_primary = d->kept_primary;
+    d->ev_used = 0; d->frame_ev_used = 0; d->kept_launches = 0; d->kept_samples = 0; d->kept_primary = 0;
     return MCPT_OK;
 }
 
@@ -1038,7 +1149,7 @@ int mcpt_sample_radiance(mcpt_device* d, uint64_t seed, const int32_t* pix, cons
     if (e == hipSuccess) e = hipMemcpyAsync(d_pix, pix, size_t(n) * 4, hipMemcpyHostToDevice, d->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_k, k, size_t(n) * 4, hipMemcpyHostToDevice, d->stream);
     if (e == hipSuccess) {
-        launch_sample_radiance(d->ds, seed, d->dirs, d_pix, d_k, n, d_rgb, d->ctr, d->stream);
+        launch_sample_radiance(d->ds, seed, d->dirs, d_pix, d_k, n, d_rgb, d->slot[0].ctr, d->stream);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_rgb, size_t(n) * 24, hipMemcpyDeviceToHost, d->stream);

@@ -42,34 +42,50 @@ def scatter_into_frame(frame_flat, bufs, pixel_lists):
 
 
 class DistributedRenderer:
-    """generateImg over `world` GPUs of one node; rank r drives GPU `local_rank`."""
+    """generateImg over `world` GPUs of one node; rank r drives GPU `local_rank`.
+    pipeline=True: a renderer of frame SEQUENCES -- consecutive frames alternate between two frame buffers, two streams and the
+    device's two frame slots (RENDER_PIPELINE | RENDER_KEEP_STATS), so the latency-bound tail of one frame overlaps the head of
+    the next and no frame waits for its statistics; read them with device.collect_stats() after a torch.cuda.synchronize()."""
 
-    def __init__(self, scene, device, rank=0, world=1, tile_w=0, tile_h=0, torch_device=None, stage_on_cpu=False):
+    def __init__(self, scene, device, rank=0, world=1, tile_w=0, tile_h=0, torch_device=None, stage_on_cpu=False, pipeline=False, gather=True):
         self.scene, self.device, self.rank, self.world = scene, device, rank, world
         self.stage_on_cpu = stage_on_cpu
+        self.gather = gather                # False: this rank's tiles only, no exchange (one rank's share of an N-way frame, for timing)
         self.tile_w, self.tile_h = tile_w, tile_h
         self.torch_device = torch_device
-        i = scene.info
         self.H, self.W = device.height, device.width      # the frame the device writes (fixed when it was created)
-        self.frame = torch.zeros((self.H * self.W, 3), dtype=torch.float64, device=torch_device)
+        self.pipeline = bool(pipeline) and torch_device is not None and torch_device.type == "cuda"
+        n_frames = 2 if self.pipeline else 1
+        self.frames = [torch.zeros((self.H * self.W, 3), dtype=torch.float64, device=torch_device) for _ in range(n_frames)]
+        self.streams = [torch.cuda.Stream(device=torch_device) for _ in range(2)] if self.pipeline else None
+        self.turn = 0
+        self.frame = self.frames[0]
         self.pixel_lists = None
         self.counts = [self.H * self.W]
-        if world > 1:
+        if world > 1 and gather:
             lists = [scene.owned_pixels(r, world, tile_w, tile_h) for r in range(world)]
             self.counts = [int(l.shape[0]) for l in lists]
             self.pixels = torch.from_numpy(lists[rank].astype(np.int64)).to(torch_device)
             if rank == 0:
                 self.pixel_lists = [torch.from_numpy(l.astype(np.int64)).to(torch_device) for l in lists]
 
-    def render(self, spp, seed=0, stats=None, flags=0):
-        """Renders this rank's tiles on the current torch stream and gathers; returns the [H,W,3] tensor on rank 0."""
+    def _render_on_current_stream(self, frame, spp, seed, stats, flags):
         stream = torch.cuda.current_stream(self.torch_device).cuda_stream
-        self.device.render_device(self.frame.data_ptr(), spp, seed, self.rank, self.world, self.tile_w, self.tile_h,
-                                  flags, stats, stream)
-        if self.world == 1:
-            return self.frame.view(self.H, self.W, 3)
-        bufs = gather_frame(self.frame, self.pixels, self.counts, self.rank, self.world, stage_on_cpu=self.stage_on_cpu)
+        self.device.render_device(frame.data_ptr(), spp, seed, self.rank, self.world, self.tile_w, self.tile_h, flags, stats, stream)
+        if self.world == 1 or not self.gather:
+            return frame.view(self.H, self.W, 3)
+        bufs = gather_frame(frame, self.pixels, self.counts, self.rank, self.world, stage_on_cpu=self.stage_on_cpu)
         if self.rank != 0:
             return None
-        scatter_into_frame(self.frame, bufs, self.pixel_lists)
-        return self.frame.view(self.H, self.W, 3)
+        scatter_into_frame(frame, bufs, self.pixel_lists)
+        return frame.view(self.H, self.W, 3)
+
+    def render(self, spp, seed=0, stats=None, flags=0):
+        """Renders this rank's tiles and gathers; returns the [H,W,3] tensor on rank 0 (pipelined: valid once its stream has
+        finished -- torch.cuda.synchronize() -- and until the frame after next is started)."""
+        if not self.pipeline:
+            return self._render_on_current_stream(self.frame, spp, seed, stats, flags)
+        from .api import RENDER_KEEP_STATS, RENDER_PIPELINE
+        self.turn ^= 1
+        with torch.cuda.stream(self.streams[self.turn]):
+            return self._render_on_current_stream(self.frames[self.turn], spp, seed, None, flags | RENDER_KEEP_STATS | RENDER_PIPELINE)

@@ -459,6 +459,47 @@ def test_multi_device_frame_equals_single_device(mcpt):
     sc.close()
 
 
+def test_pipelined_frames_equal_sequential_frames(mcpt):
+    """A sequence of frames with two in flight (RENDER_PIPELINE | RENDER_KEEP_STATS: the device's two frame slots, two streams, two
+    frame buffers; no frame waits for its statistics) gives, frame for frame, the bits of the same frames rendered one at a time,
+    and the statistics collected afterwards are the sums of theirs.  (Streams and buffers through the HIP runtime directly: what
+    montecarlopathtracing_amd.dist.DistributedRenderer(pipeline=True) does with torch's.)"""
+    import hip_rt
+    sc = mcpt.Scene(SCENES, "cornell-box", width=640, height=360)
+    dev = mcpt.Device(sc, 0)
+    seeds = (1, 2, 3, 4, 5)
+    want, sums = [], {"samples": 0, "rays_shadow": 0, "rays_bounce": 0, "shade_calls": 0, "launches": 0, "rays_primary": 0, "dom_rays": 0}
+    for sd in seeds:
+        st = mcpt.Stats()
+        want.append(dev.generateImg(24, seed=sd, stats=st))
+        for k in sums:
+            sums[k] += getattr(st, k)
+    nbytes = 640 * 360 * 3 * 8
+    streams = [hip_rt.Stream(), hip_rt.Stream()]
+    frames = [hip_rt.DeviceBuffer(nbytes), hip_rt.DeviceBuffer(nbytes)]
+    got = [np.zeros((360, 640, 3)) for _ in seeds]
+    for i, sd in enumerate(seeds):
+        t = i & 1
+        dev.render_device(frames[t].ptr.value, 24, sd, flags=mcpt.RENDER_PIPELINE | mcpt.RENDER_KEEP_STATS, stream=streams[t].h.value)
+        frames[t].to_host_async(got[i], streams[t].h)            # before the frame after next overwrites the buffer (same stream)
+    for st_ in streams:
+        st_.synchronize()
+    for a, b in zip(want, got):
+        assert np.array_equal(_bits(a), _bits(b))
+    st = dev.collect_stats()
+    for k in sums:
+        assert getattr(st, k) == sums[k], (k, getattr(st, k), sums[k])
+    assert st.ms_trace > 0 and st.ms_total >= st.ms_trace
+    again = dev.collect_stats()
+    assert again.samples == 0 and again.rays_shadow == 0 and again.ms_total == 0        # collected means started over
+    assert np.array_equal(_bits(dev.generateImg(24, seed=3)), _bits(want[2]))            # and the plain entry still works afterwards
+    for f in frames:
+        f.free()
+    for st_ in streams:
+        st_.destroy()
+    dev.close(); sc.close()
+
+
 def test_cpp_drop_in_render_scene(mcpt, tmp_path):
     """The C++ surface a user of the reference switches to: a main() that includes include/mtpc_compat.hpp and calls
     render_scene(path, filename, N) exactly like MTPC/MTPC.cpp:78, compiled here with g++ against libmcpt.so, and the mtpc

@@ -1,5 +1,7 @@
-mkdir -p gpurun_out/r2l
-for v in diagshare diagnoshare; do
-MCPT_PRINT_DIAG=1 MCPT_LIB=$PWD/montecarlopathtracing_amd/csrc/variants/libmcpt_$v.so timeout -k 10 200 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r2l/$v.json 2> gpurun_out/r2l/$v.err
-echo $v; grep "trace diag" gpurun_out/r2l/$v.err | tail -1
-done
+mkdir -p gpurun_out/r2n
+export TMPDIR=/tmp
+root=$PWD
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace -d $root/gpurun_out/r2n/kt8 -o kt --output-format csv -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --sim-world 8 > $root/gpurun_out/r2n/kt8.log 2>&1
+cd $root
+tail -1 gpurun_out/r2n/kt8.log | cut -c1-200
