@@ -235,7 +235,7 @@ def test_wavefront_iterations_against_megakernel_and_oracle(pair, oracle, mcpt, 
         a = dev.generateImg(spp, seed=3, stats=st)
         b = dev.generateImg(spp, seed=3, flags=mcpt.RENDER_MEGAKERNEL)
         assert np.array_equal(_bits(a), _bits(b)), "%d channels differ from the megakernel" % int((_bits(a) != _bits(b)).sum())
-        assert st.launches >= 8, st.launches                  # the bounce loop really ran as wavefront iterations
+        assert st.launches >= 5, st.launches                  # the bounce loop really ran as wavefront iterations
         if mode == "fast" and finish_paths == "0":
             assert st.dom_rays > 0.9 * (st.rays_shadow + st.rays_bounce)     # ... and its rays went through k_wf_trace
         ref = osc.render(spp, seed=3)
