@@ -66,8 +66,6 @@ typedef struct {
     double   ms_trace, ms_total;                     /* device time of the dominant kernel / whole call (HIP events) */
     int32_t  launches;                               /* launches of the dominant kernel */
     int32_t  max_depth;
-    uint64_t rays_shadow_listed;                     /* since MCPT_VERSION 102: of rays_shadow, the first-vertex shadow rays answered from their
-                                                        pixel's triangle list (k_wf_shadow_first) instead of a walk of the hierarchy */
 } mcpt_stats;
 
 typedef struct {

@@ -31,7 +31,7 @@ class Stats(C.Structure):
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("shade_calls", C.c_uint64),
                 ("samples", C.c_uint64), ("shadow_skipped", C.c_uint64), ("dom_rays", C.c_uint64),
                 ("dom_node_visits", C.c_uint64), ("dom_tri_tests", C.c_uint64), ("ms_trace", C.c_double), ("ms_total", C.c_double),
-                ("launches", C.c_int32), ("max_depth", C.c_int32), ("rays_shadow_listed", C.c_uint64)]
+                ("launches", C.c_int32), ("max_depth", C.c_int32)]
 
     @property
     def rays(self):

@@ -90,8 +90,6 @@ struct mcpt_device {
     // scene arrays
     DNode* nodes = nullptr; DTri* tris = nullptr; DTriShade* shade = nullptr; DMaterial* materials = nullptr;
     DLight* lights = nullptr; DLightTri* light_tris = nullptr; double* light_cdf = nullptr; uint8_t* texels = nullptr;
-    DLightReach* light_reach = nullptr;
-    bool shadow_lists = true;              // first-vertex shadow rays answered from per-pixel triangle lists (MCPT_SHADOW_LISTS=0: all traced)
     FastNode* fast_nodes = nullptr; DTri* fast_tris = nullptr; CwNode* cw_nodes = nullptr;
     int trace_mode = MCPT_TRACE_FAST;
     int32_t* d_order = nullptr;            // leaf -> .obj face (device build keeps it for read-back)
@@ -116,9 +114,6 @@ struct mcpt_device {
         void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
         int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
         PrimarySurface* surf = nullptr; int64_t surf_cap = 0;   // first-vertex record per hit pixel of the chunk
-        int32_t* sl_count = nullptr; int64_t sl_count_cap = 0;  // shadow lists per (pixel of the chunk, light)
-        int32_t* sl_tris = nullptr; int64_t sl_tris_cap = 0;
-        uint32_t* sl_unresolved = nullptr; int64_t sl_unresolved_cap = 0;
         WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
         TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
         long long* slow_list = nullptr;
@@ -447,11 +442,11 @@ void mcpt_device_free(mcpt_device* d)
 {
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
-    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->light_reach, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes, d->d_order,
+    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes, d->d_order,
                     d->dirs, d->pixels};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& f : d->slot) {
-        void* q[] = {f.hits, f.rad, f.wf_ws, f.hit_slots, f.surf, f.sl_count, f.sl_tris, f.sl_unresolved, f.wf_counts, f.queue, f.slow_list, f.ctr};
+        void* q[] = {f.hits, f.rad, f.wf_ws, f.hit_slots, f.surf, f.wf_counts, f.queue, f.slow_list, f.ctr};
         for (void* p : q) if (p) (void)hipFree(p);
         if (f.done) (void)hipEventDestroy(f.done);
     }
@@ -588,34 +583,8 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         }
         lights[i] = dl;
     }
-    // where each light's samples can land (DLightReach): the area pick draws from [0, area0) (Q1), so triangle j is reachable iff
-    // its CDF interval starts below area0; a pick beyond the light's own area leaves xl = (0,0,0) (pathTracing.cpp:187-199)
-    std::vector<DLightReach> reach(s.lights.size());
-    for (size_t i = 0; i < s.lights.size(); i++) {
-        const LightRec& l = s.lights[i];
-        const MaterialRec& m = s.materials[l.material];
-        DLightReach r;
-        for (int k = 0; k < 3; k++) { r.lo[k] = 1e300; r.hi[k] = -1e300; }
-        auto add = [&](double x, double y, double z) {
-            const double q[3] = {x, y, z};
-            for (int k = 0; k < 3; k++) { r.lo[k] = std::min(r.lo[k], q[k]); r.hi[k] = std::max(r.hi[k], q[k]); }
-        };
-        bool may_fail = m.faces.empty() || !l.cdf_sorted || !(s.area0 <= l.cdf.back());
-        for (size_t j = 0; j < m.faces.size(); j++) {
-            const double start = j ? l.cdf[j - 1] : 0.0;
-            if (l.cdf_sorted && !(start < s.area0)) break;
-            const FaceRec& f = s.faces[m.faces[j]];
-            for (int c = 0; c < 3; c++) add(f.v[c].x, f.v[c].y, f.v[c].z);
-        }
-        if (may_fail) add(0, 0, 0);
-        int reachable = 0;
-        for (size_t j = 0; j < m.faces.size(); j++) if (!l.cdf_sorted || (j ? l.cdf[j - 1] : 0.0) < s.area0) reachable++;
-        r.use_lists = reachable <= MCPT_SHADOW_LIST_MAX / 2 ? 1 : 0;       // the light's own triangles are always in the list
-        r.pad[0] = r.pad[1] = r.pad[2] = 0;
-        reach[i] = r;
-    }
     if ((rc = upload(mats, &d->materials)) || (rc = upload(lights, &d->lights)) || (rc = upload(ltris, &d->light_tris)) ||
-        (rc = upload(lcdf, &d->light_cdf)) || (rc = upload(texels, &d->texels)) || (rc = upload(reach, &d->light_reach)))
+        (rc = upload(lcdf, &d->light_cdf)) || (rc = upload(texels, &d->texels)))
         return rc;
 
     // result-identical fast structure: SAH hierarchy built on the host from the leaf order (accel_build.cpp), permuted triangle
@@ -693,7 +662,6 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
     }
     if (const char* e = std::getenv("MCPT_FINISH_PATHS")) d->finish_threshold = std::atoll(e);
-    if (const char* e = std::getenv("MCPT_SHADOW_LISTS")) d->shadow_lists = std::atoi(e) != 0;
     init_launch_cfg(d->cfg);
     if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
         const double v = std::atof(gb);
@@ -702,7 +670,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
 
     DScene& S = d->ds;
     S.nodes = d->nodes; S.tris = d->tris; S.shade = d->shade; S.materials = d->materials; S.lights = d->lights;
-    S.light_tris = d->light_tris; S.light_cdf = d->light_cdf; S.light_reach = d->light_reach; S.texels = d->texels;
+    S.light_tris = d->light_tris; S.light_cdf = d->light_cdf; S.texels = d->texels;
     S.t = t; S.Lv = bi.Lv; S.Level = bi.Level; S.Nr = bi.Nr;
     S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
     S.area0 = s.area0;
@@ -777,7 +745,6 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
     s->node_visits = c.node_visits; s->tri_tests = c.tri_tests; s->shade_calls = c.shade_calls; s->samples = c.samples;
     s->shadow_skipped = c.shadow_skipped;
     s->dom_rays = c.trace_rays; s->dom_node_visits = c.trace_nodes; s->dom_tri_tests = c.trace_tris;
-    s->rays_shadow_listed = c.pad[13];
     if (std::getenv("MCPT_PRINT_DIAG")) {
         const double tot = double(c.pad[5] + c.pad[6] + c.pad[7]);
         std::fprintf(stderr, "trace diag: inner iters %llu lanes %.1f/64 | tri iters %llu lanes %.1f/64 | idle lanes/iter %.1f | wave time: refill %.1f%% inner %.1f%% tri %.1f%% | cycles/inner iter %.0f cycles/tri iter %.0f\n",
@@ -785,7 +752,7 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
                      (c.pad[0] + c.pad[2]) ? double(c.pad[4]) / (c.pad[0] + c.pad[2]) : 0.0,
                      tot ? 100.0 * c.pad[5] / tot : 0.0, tot ? 100.0 * c.pad[6] / tot : 0.0, tot ? 100.0 * c.pad[7] / tot : 0.0,
                      c.pad[0] ? double(c.pad[6]) / c.pad[0] : 0.0, c.pad[2] ? double(c.pad[7]) / c.pad[2] : 0.0);
-        std::fprintf(stderr, "rays deferred to the exact walk by k_wf_trace: %llu of %llu; first-vertex shadow rays answered from lists: %llu\n", c.pad[12], c.trace_rays, c.pad[13]);
+        std::fprintf(stderr, "rays deferred to the exact walk by k_wf_trace: %llu of %llu\n", c.pad[12], c.trace_rays);
         const double lt = double(c.pad[8] + c.pad[9] + c.pad[10]);
         std::fprintf(stderr, "logic diag: resolve %.1f%% compaction %.1f%% shade %.1f%% | cycles per wave: %.0f / %.0f / %.0f (waves %llu)\n",
                      lt ? 100.0 * c.pad[8] / lt : 0.0, lt ? 100.0 * c.pad[9] / lt : 0.0, lt ? 100.0 * c.pad[10] / lt : 0.0,
@@ -954,18 +921,11 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
     int rc = grow(&f.hit_slots, &f.hit_slots_cap, chunk_slots);
     if (rc) return rc;
     if ((rc = grow(&f.surf, &f.surf_cap, chunk_slots))) return rc;
-    const bool lists = d->shadow_lists && fast && nl > 0 && double(cap) * nl < 4.0e9;      // (ray ids of the compact list are 32-bit)
-    if (lists) {
-        if ((rc = grow(&f.sl_unresolved, &f.sl_unresolved_cap, cap * nl))) return rc;
-        if ((rc = grow(&f.sl_count, &f.sl_count_cap, chunk_slots * nl))) return rc;
-        if ((rc = grow(&f.sl_tris, &f.sl_tris_cap, chunk_slots * nl * MCPT_SHADOW_LIST_MAX))) return rc;
-    }
     WfArgs a{};
     WfState A, B;
     if (!wf_carve(f.wf_ws, f.wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
     a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = f.hit_slots; a.surf = f.surf; a.hits = f.hits;
     a.dirs = d->dirs; a.rad = f.rad; a.counts = f.wf_counts; a.ctr = f.ctr; a.tris = d->tris;
-    a.use_lists = lists ? 1 : 0; a.sl_count = f.sl_count; a.sl_tris = f.sl_tris; a.sl_unresolved = f.sl_unresolved;
     a.finish_below = fast ? unsigned(std::min<long long>(std::max<long long>(d->finish_threshold, 0), 1ll << 30)) : 0u;
     // Iterations are enqueued without waiting for their counts: every kernel reads its input count from the device slot the
     // previous one wrote.  The host looks at a count only every few iterations (to stop, and to size the next grids).
@@ -993,10 +953,6 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
         a.counts_in = &f.wf_counts[0];
         launch_primary_surface(d->ds, a, f.surf, n_slots, st);      // what the samples of a pixel share at their first vertex
         HIP_TRY(hipGetLastError());
-        if (lists) {                                                 // ... and what their shadow rays can meet on the way to each light
-            launch_shadow_lists(d->ds, a, f.sl_count, f.sl_tris, n_slots, st);
-            HIP_TRY(hipGetLastError());
-        }
         for (int depth = 0; depth < MCPT_MAX_DEPTH && n_upper > 0; depth++) {
             a.depth = depth;
             a.counts_in = &f.wf_counts[depth]; a.count_mul = depth == 0 ? unsigned(spp) : 1u;
@@ -1027,10 +983,6 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
                 HIP_TRY(hipGetLastError());
             }
             const long long n_trace = look ? (long long)n_grid : n_launch;
-            if (lists && depth == 0) {                               // first-vertex shadow rays: answered from the pixel's list where it can
-                launch_wf_shadow_first(d->ds, a, n_trace, st);
-                HIP_TRY(hipGetLastError());
-            }
             std::pair<hipEvent_t, hipEvent_t>* pr = nullptr;
             if (timed || keep) { if ((rc = next_pair(pr))) return rc; HIP_TRY(hipEventRecord(pr->first, st)); }
             launch_wf_trace(d->ds, a, n_trace, fast, f.queue, f.slow_list, d->slow_cap, st, d->cfg);

@@ -85,13 +85,6 @@ struct alignas(16) DLight {
     int32_t material, ntri, first, cdf_sorted;   // first = offset into light_tris / light_cdf
 };
 
-// Where light l's samples can land: the bounding box of the triangles its area pick can reach (with the frozen range of Q1 that is
-// the first few triangles of lights 2..n; the origin is included when the pick can fail, pathTracing.cpp:189-199 leaves xl = 0).
-struct alignas(16) DLightReach {
-    double lo[3], hi[3];
-    int32_t use_lists, pad[3];     // 0: too many reachable triangles for a per-pixel list to pay (a 760-triangle sphere): its rays are walked
-};
-
 struct DCamera {                                   // generateImg's frame, pathTracing.cpp:276-294
     double eye[3], start_point[3], pdx[3], pdy[3];
     int32_t width, height;
@@ -105,7 +98,6 @@ struct DScene {
     const DLight* lights;
     const DLightTri* light_tris;
     const double* light_cdf;
-    const DLightReach* light_reach;
     const uint8_t* texels;
     DFast fast;
     int32_t t, Lv, Level, Nr, num_lights, num_materials;

@@ -289,7 +289,7 @@ int mcpt_multi_render_device(mcpt_multi* m, const mcpt_render_params* p, double*
             stats->node_visits += s.node_visits; stats->tri_tests += s.tri_tests; stats->shade_calls += s.shade_calls;
             stats->samples += s.samples; stats->shadow_skipped += s.shadow_skipped;
             stats->dom_rays += s.dom_rays; stats->dom_node_visits += s.dom_node_visits; stats->dom_tri_tests += s.dom_tri_tests;
-            stats->launches += s.launches; stats->rays_shadow_listed += s.rays_shadow_listed;
+            stats->launches += s.launches;
             stats->ms_trace = std::max(stats->ms_trace, s.ms_trace);
             stats->max_depth = std::max(stats->max_depth, s.max_depth);
         }

@@ -205,18 +205,10 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
 struct WfRaySource {
     WfArgs a;
     long long n_paths;
-    // With per-pixel shadow lists the first iteration's shadow rays are the compact list k_wf_shadow_first left (then come the
-    // bounce rays); otherwise slot q = l * n_paths + j.
-    __device__ __forceinline__ bool listed() const { return a.use_lists && a.depth == 0; }
-    __device__ __forceinline__ long long total() const { return listed() ? (long long)a.counts->pad[1] + n_paths : n_paths * (a.nl + 1); }
+    __device__ __forceinline__ long long total() const { return n_paths * (a.nl + 1); }
     // (l, j) of slot q without a 64-bit division: nl is small
     __device__ __forceinline__ void split(long long q, int& l, long long& j) const
     {
-        if (listed()) {
-            const long long n_un = a.counts->pad[1];
-            if (q >= n_un) { l = a.nl; j = q - n_un; return; }
-            q = a.sl_unresolved[q];
-        }
         l = 0; j = q;
         while (j >= n_paths) { j -= n_paths; l++; }
     }
@@ -493,213 +485,6 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
     flush_stats(a.ctr, ls);
 }
 
-// ---------------------------------------------------------------------------------------------- first-vertex shadow rays
-// All samples of a pixel shade the same first vertex p (the primary ray has no jitter, pathTracing.cpp:306-308) and send their shadow
-// rays from p + 0.01 d to a point of the same light (:187-208).  Every such ray runs from the ball A = B(p, 0.01) into the box B of
-// the light's reachable sample points, so whatever it can meet on the way lies in the convex hull of A and B.  k_shadow_lists walks
-// the culling hierarchy once per (hit pixel, light) and lists the triangles whose own box touches that hull (conservatively: the
-// hull's projections on the three coordinate planes, every box padded); k_wf_shadow_first then gives every first-vertex shadow
-// ray the reference's answer from that list alone -- the lexicographic minimum of (t_k, k) over the listed triangles that pass the
-// reference's own-box and triangle tests -- provided the winner lies before the ray's exit from B, padded by more than the
-// distance pruning margin of trace_fast.hpp: any candidate of the whole scene that could beat it then has its hit point inside the
-// hull and is therefore in the list.  Rays that give no such winner (and pixels with more than MCPT_SHADOW_LIST_MAX entries) are
-// marked MCPT_SHADOW_UNRESOLVED and walked by k_wf_trace like any other ray.  Same tests on the same candidates: same bits.
-struct Hull {               // convex hull of two boxes, as 12 supporting lines of its three coordinate-plane projections
-    double ulo[3], uhi[3];  // box of the union
-    double nu[12], nv[12], c[12];   // line k of plane k / 4: nu * x_u + nv * x_v <= c holds on the hull (c = -inf: line unused)
-};
-__device__ __forceinline__ void hull_make(const double alo[3], const double ahi[3], const double blo[3], const double bhi[3], double tol, Hull& H)
-{
-    for (int a = 0; a < 3; a++) { H.ulo[a] = fmin(alo[a], blo[a]); H.uhi[a] = fmax(ahi[a], bhi[a]); }
-    for (int pl = 0; pl < 3; pl++) {
-        const int u = pl == 2 ? 1 : 0, v = pl == 0 ? 1 : 2;         // planes (x,y), (x,z), (y,z)
-        for (int k = 0; k < 4; k++) {
-            const double au = (k & 1) ? ahi[u] : alo[u], av = (k & 2) ? ahi[v] : alo[v];
-            const double bu = (k & 1) ? bhi[u] : blo[u], bv = (k & 2) ? bhi[v] : blo[v];
-            double nu = -(bv - av), nv = bu - au;                    // normal of the line through corresponding corners
-            const int id = pl * 4 + k;
-            H.nu[id] = 0; H.nv[id] = 0; H.c[id] = __builtin_inf();   // unused unless it supports the hull
-            if (nu == 0.0 && nv == 0.0) continue;
-            // both rectangles on one side?  max / min of n.x over a rectangle = sum of per-axis extremes
-            const double ca = nu * au + nv * av;
-            double hi = fmax(fmax(nu * alo[u], nu * ahi[u]) + fmax(nv * alo[v], nv * ahi[v]), fmax(nu * blo[u], nu * bhi[u]) + fmax(nv * blo[v], nv * bhi[v]));
-            double lo = fmin(fmin(nu * alo[u], nu * ahi[u]) + fmin(nv * alo[v], nv * ahi[v]), fmin(nu * blo[u], nu * bhi[u]) + fmin(nv * blo[v], nv * bhi[v]));
-            if (hi <= ca + tol) { H.nu[id] = nu; H.nv[id] = nv; H.c[id] = ca + tol; }
-            else if (lo >= ca - tol) { H.nu[id] = -nu; H.nv[id] = -nv; H.c[id] = -ca + tol; }
-        }
-    }
-}
-// false only if the box certainly misses the hull
-__device__ __forceinline__ bool hull_may_touch(const Hull& H, const double lo[3], const double hi[3])
-{
-    for (int a = 0; a < 3; a++) if (lo[a] > H.uhi[a] || hi[a] < H.ulo[a]) return false;
-    for (int pl = 0; pl < 3; pl++) {
-        const int u = pl == 2 ? 1 : 0, v = pl == 0 ? 1 : 2;
-        for (int k = 0; k < 4; k++) {
-            const int id = pl * 4 + k;
-            const double least = fmin(H.nu[id] * lo[u], H.nu[id] * hi[u]) + fmin(H.nv[id] * lo[v], H.nv[id] * hi[v]);
-            if (least > H.c[id]) return false;                      // the whole box is outside a supporting line
-        }
-    }
-    return true;
-}
-
-__global__ void __launch_bounds__(64) k_shadow_lists(DScene S, WfArgs a, int32_t* __restrict__ sl_count, int32_t* __restrict__ sl_tris)
-{
-    const unsigned int n_hit = a.counts_in->n_next;
-    const int nl = a.nl;
-    const DFast& F = S.fast;
-    const long long total = (long long)n_hit * nl;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-        const unsigned int h = (unsigned int)(g / nl);
-        const int l = (int)(g % nl);
-        const PrimarySurface* ps = a.surf + h;
-        const long long at = (long long)(ps->slot - a.first_slot) * nl + l;
-        int32_t* out = sl_tris + at * MCPT_SHADOW_LIST_MAX;
-        if (!F.enabled || S.materials[ps->material].light >= 0 || !S.light_reach[l].use_lists) { sl_count[at] = -1; continue; }   // (an emitter sends no shadow rays)
-        const double scale = fmax(F.absmax, fmax(fabs(ps->p[0]), fmax(fabs(ps->p[1]), fabs(ps->p[2]))));
-        const double pad = 1e-7 * scale;
-        // A: the ray origins p + 0.01 d, |d| = 1 up to rounding.  B: the light's reachable points, grown by more than the largest
-        // distance margin a listed ray may have (1e-9 * scale * 1e6, trace_fast.hpp) so that "before the exit from B" covers it.
-        const double grow = 4.0e-3 * scale + pad;
-        double alo[3], ahi[3], blo[3], bhi[3];
-        const DLightReach lr = S.light_reach[l];
-        for (int k = 0; k < 3; k++) {
-            alo[k] = ps->p[k] - (0.0100001 + pad); ahi[k] = ps->p[k] + (0.0100001 + pad);
-            blo[k] = lr.lo[k] - grow; bhi[k] = lr.hi[k] + grow;
-        }
-        Hull H;
-        hull_make(alo, ahi, blo, bhi, 1e-9 * scale * scale, H);
-        int count = 0;
-        int stack[MCPT_FAST_STACK];
-        int sp = 0, cur = 0;
-        bool overflow = false;
-        for (;;) {
-            if (cur >= 0) {
-                const CwNode* nd = F.cw + cur;
-                int nxt = MCPT_FAST_EMPTY;
-                for (int c = 0; c < 4; c++) {
-                    const int ref = nd->child[c];
-                    if (ref == MCPT_FAST_EMPTY) continue;
-                    double lo[3], hi[3];
-                    for (int k = 0; k < 3; k++) {                    // the decoded box contains the child's fp64 box
-                        const double sc = __builtin_ldexp(1.0, (int)nd->e[k]);
-                        lo[k] = (double)nd->p[k] + (double)((nd->qlo[k] >> (8 * c)) & 255u) * sc - pad;
-                        hi[k] = (double)nd->p[k] + (double)((nd->qhi[k] >> (8 * c)) & 255u) * sc + pad;
-                    }
-                    if (!hull_may_touch(H, lo, hi)) continue;
-                    if (nxt == MCPT_FAST_EMPTY) nxt = ref;
-                    else if (sp < MCPT_FAST_STACK) stack[sp++] = ref;
-                    else overflow = true;
-                }
-                if (nxt == MCPT_FAST_EMPTY) { if (sp == 0) break; nxt = stack[--sp]; }
-                cur = nxt;
-            } else {
-                const int ref = -1 - cur;
-                const int first = ref >> 4, n = (ref & 7) + 1;
-                for (int i = 0; i < n; i++) {
-                    const DTri* tr = F.tris + first + i;
-                    double lo[3], hi[3];
-                    for (int k = 0; k < 3; k++) {
-                        lo[k] = fmin(fmin(tr->v1[k], tr->v2[k]), tr->v3[k]) - pad;
-                        hi[k] = fmax(fmax(tr->v1[k], tr->v2[k]), tr->v3[k]) + pad;
-                    }
-                    if (!hull_may_touch(H, lo, hi)) continue;
-                    if (count < MCPT_SHADOW_LIST_MAX) out[count] = first + i;
-                    count++;
-                }
-                if (count > MCPT_SHADOW_LIST_MAX || sp == 0) break;      // too many: the pixel's rays are walked
-                cur = stack[--sp];
-            }
-        }
-        sl_count[at] = (overflow || count > MCPT_SHADOW_LIST_MAX) ? -1 : count;
-    }
-}
-
-// one lane per first-vertex shadow ray (l, j)
-__global__ void __launch_bounds__(256) k_wf_shadow_first(DScene S, WfArgs a)
-{
-    const long long n_paths = a.counts->n_next;
-    const int nl = a.nl;
-    const long long total = n_paths * nl;
-    const DFast& F = S.fast;
-    LaneStats ls;
-    const int lane = threadIdx.x & 63;
-    const long long total_round = (total + 255) / 256 * 256;       // whole waves take part in the ballots below
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total_round; q += (long long)gridDim.x * 256) {
-        bool unresolved = false;
-        uint32_t slot_id = 0;
-      do {
-        if (q >= total) break;
-        const int l = (int)(q / n_paths);
-        const long long j = q - (long long)l * n_paths;
-        const int expect = a.out.expect[(long long)l * a.cap + j];
-        if (expect == -2) break;                                     // no shadow ray
-        int result = MCPT_SHADOW_UNRESOLVED;
-        const int local = a.out.id[j] / a.spp;                        // chunk-local pixel slot
-        const long long at = (long long)local * nl + l;
-        const int count = a.sl_count[at];
-        const PrimaryHit* ph = a.hits + (a.first_slot + local);
-        Ray r;
-        r.d = ldc(a.rays.d + (long long)l * 3 * a.cap, a.cap, j);
-        r.o = mk(ph->p[0], ph->p[1], ph->p[2]) + r.d * 0.01;
-        if (count >= 0 && fast_path_ok(F, r)) {
-            const V3 rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
-            const double rmax = fmax(fmax(fabs(rcp.x), fabs(rcp.y)), fabs(rcp.z));
-            const double scale = fmax(fmax(F.absmax, fabs(r.o.x)), fmax(fabs(r.o.y), fabs(r.o.z)));
-            if (rmax <= 1e6) {
-                const double margin = 1.0000001e-9 * scale * rmax;
-                // where the ray leaves the grown box of the light (a little early rather than late)
-                const DLightReach lr = S.light_reach[l];
-                const double grow = 4.0e-3 * fmax(F.absmax, fmax(fabs(ph->p[0]), fmax(fabs(ph->p[1]), fabs(ph->p[2]))));
-                const double ex = fmax((lr.lo[0] - grow - r.o.x) * rcp.x, (lr.hi[0] + grow - r.o.x) * rcp.x);
-                const double ey = fmax((lr.lo[1] - grow - r.o.y) * rcp.y, (lr.hi[1] + grow - r.o.y) * rcp.y);
-                const double ez = fmax((lr.lo[2] - grow - r.o.z) * rcp.z, (lr.hi[2] + grow - r.o.z) * rcp.z);
-                const double s_exit = fmin(fmin(ex, ey), ez) * (1.0 - 1e-9);
-                const int32_t* list = a.sl_tris + at * MCPT_SHADOW_LIST_MAX;
-                bool found = false, undecided = false;
-                int best = -1;
-                double best_ta = 0;
-                V3 best_p = mk(0, 0, 0);
-                for (int i = 0; i < count; i++) {
-                    const DTri* tr = F.tris + list[i];
-                    V3 p;
-                    ls.tris++;
-                    if (!tri_hit(tr, r, p)) continue;
-                    const double ta = (p.x - r.o.x) * rcp.x;         // rank of t_k, as in trace_persistent.hpp
-                    if (!(ta > 0.0)) continue;
-                    const double band = best_ta * 0x1p-47;
-                    if (!found || ta < best_ta - band) { found = true; best = list[i]; best_ta = ta; best_p = p; }
-                    else if (!(ta > best_ta + band)) {
-                        if (own_box_hit(tr, r, rcp)) {
-                            const double t_new = (p.x - r.o.x) / r.d.x, t_old = (best_p.x - r.o.x) / r.d.x;
-                            if (t_new < t_old || (t_new == t_old && tr->leaf < F.tris[best].leaf)) { best = list[i]; best_ta = ta; best_p = p; }
-                        }
-                    }
-                }
-                if (found && !own_box_hit(F.tris + best, r, rcp)) undecided = true;     // a leader that is no candidate may have hidden one
-                if (found && !undecided && (best_ta + best_ta * 0x1p-40) + margin <= s_exit) result = F.tris[best].material;
-            }
-        }
-        if (result != MCPT_SHADOW_UNRESOLVED) { ls.primary++; a.out.hit_mat[(long long)l * a.cap + j] = result; }   // (counted below)
-        unresolved = result == MCPT_SHADOW_UNRESOLVED;
-        slot_id = (uint32_t)q;
-      } while (0);
-        // rays left to the trace kernel: one compact list (wave ballot + prefix, one atomic per wave; the order does not matter)
-        const unsigned long long bal = __ballot(unresolved);
-        if (bal) {
-            unsigned int base = 0;
-            if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&a.counts->pad[1], (unsigned int)__popcll(bal));
-            base = __shfl(base, __ffsll((long long)bal) - 1, 64);
-            if (unresolved) a.sl_unresolved[base + __popcll(bal & ((1ull << lane) - 1ull))] = slot_id;
-        }
-    }
-    if (a.ctr) {
-        const unsigned long long n = wave_sum(ls.primary), t = wave_sum(ls.tris);
-        if ((threadIdx.x & 63) == 0 && (n || t)) { if (n) atomicAdd(&a.ctr->pad[13], n); if (t) atomicAdd(&a.ctr->tri_tests, t); }
-    }
-}
-
 // one PrimarySurface per hit pixel of the chunk (same arithmetic as the per-sample code it replaces: vertex_surface)
 __global__ void k_primary_surface(DScene S, WfArgs a, PrimarySurface* __restrict__ surf)
 {
@@ -832,18 +617,6 @@ void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipSt
 {
     if (n_upper <= 0) return;
     hipLaunchKernelGGL(k_wf_finish, dim3(grid_for(n_upper, 256, unsigned(cfg.finish_grid))), dim3(256), 0, st, S, a);
-}
-
-void launch_shadow_lists(const DScene& S, const WfArgs& a, int32_t* sl_count, int32_t* sl_tris, int n_slots_upper, hipStream_t st)
-{
-    if (n_slots_upper <= 0) return;
-    hipLaunchKernelGGL(k_shadow_lists, dim3(grid_for((long long)n_slots_upper * a.nl, 64, 16384)), dim3(64), 0, st, S, a, sl_count, sl_tris);
-}
-
-void launch_wf_shadow_first(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st)
-{
-    if (n_upper <= 0) return;
-    hipLaunchKernelGGL(k_wf_shadow_first, dim3(grid_for(n_upper * a.nl, 256, 8192)), dim3(256), 0, st, S, a);
 }
 
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)

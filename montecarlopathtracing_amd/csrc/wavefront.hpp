@@ -60,8 +60,6 @@ struct WfCounts {           // one per iteration, on the device: slot 0 = hit pi
     unsigned int pad[15];
 };
 #define MCPT_WF_COUNT_SLOTS 72
-#define MCPT_SHADOW_LIST_MAX 24
-#define MCPT_SHADOW_UNRESOLVED (-3)     /* hit_mat of a first-vertex shadow ray the list could not answer */
 
 struct WfArgs {
     WfState in, out;
@@ -81,13 +79,6 @@ struct WfArgs {
     unsigned int count_mul;     // input paths = counts_in->n_next * count_mul (spp for the first pass, 1 afterwards)
     DCounters* ctr;
     const DTri* tris;           // S.tris (material of a shadow ray's hit)
-    // First-vertex shadow rays: all samples of a pixel leave the same point towards the same light, so the triangles any of them
-    // can meet before (or at) the light are collected once per (pixel, light) -- k_shadow_lists -- and k_wf_shadow_first
-    // answers those rays from the list with the reference's own tests; what it cannot answer is left to the trace kernel.
-    int use_lists;              // 0: every shadow ray goes through the trace kernel
-    const int32_t* sl_count;    // [chunk slot][nl]: entries of the list, -1 = too many (the pixel's rays are traced)
-    const int32_t* sl_tris;     // [chunk slot][nl][MCPT_SHADOW_LIST_MAX]: slots of the fast triangle array
-    uint32_t* sl_unresolved;    // first-vertex shadow rays left to the trace kernel, as l * n_paths + j; their number: counts[1].pad[1]
     // Hand-over to the finishing kernel, decided on the device: when logic(d) leaves at most this many paths, k_wf_finish
     // (launched after every logic pass) runs them to their end and trace(d), logic(d+1), ... find nothing to do.  0 = never.
     unsigned int finish_below;
@@ -102,8 +93,6 @@ void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool f
 void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool fast, TraceQueue* queue, long long* slow_list,
                      unsigned int slow_cap, hipStream_t st, const LaunchCfg& cfg);
 void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st, const LaunchCfg& cfg);
-void launch_shadow_lists(const DScene& S, const WfArgs& a, int32_t* sl_count, int32_t* sl_tris, int n_slots_upper, hipStream_t st);
-void launch_wf_shadow_first(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st);
 int persistent_grid(const void* kernel, int cus);   // blocks of 256 threads of `kernel` resident on the current device
 long long persistent_chunk(long long total, int grid_blocks);
 
