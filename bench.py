@@ -197,7 +197,7 @@ def main():
     # A renderer of a sequence of frames: two frames in flight (the device's two frame slots, two streams, two frame tensors), so
     # the latency-bound tail of frame i overlaps the head of frame i+1, and no frame waits for its statistics (they stay on the
     # device until the timed region is over).  --no-pipeline: one frame at a time, statistics read back after every frame.
-    pipeline = not args.no_pipeline and not share_gpu
+    pipeline = not args.no_pipeline and not share_gpu and world == 1     # (with a gather per frame the ranks render one frame at a time)
     if args.sim_world > 1:          # one rank's share of an N-way partition, no communication
         rr = DistributedRenderer(scene, dev, args.sim_rank, args.sim_world, torch_device=tdev, pipeline=pipeline, gather=False)
     else:
@@ -209,8 +209,17 @@ def main():
         torch.cuda.synchronize()
 
     if pipeline:                    # both frame slots get their workspace (83 GB each for the headline frame) outside the timed region
-        for _ in range(2):
-            rr.render(args.spp, args.seed)
+        try:
+            for _ in range(2):
+                rr.render(args.spp, args.seed)
+            torch.cuda.synchronize()
+        except M.McptError as e:    # not enough free HBM for two frames in flight: one at a time
+            print("pipelining off: %s" % e, file=sys.stderr)
+            pipeline = False
+            dev.close()
+            dev = M.Device(scene, local_rank, build=build_mode)
+            rr = DistributedRenderer(scene, dev, args.sim_rank if args.sim_world > 1 else rank, args.sim_world if args.sim_world > 1 else world,
+                                     torch_device=tdev, stage_on_cpu=share_gpu, pipeline=False, gather=args.sim_world <= 1)
     for _ in range(args.warmup):
         rr.render(args.spp, args.seed)
     sync()
