@@ -1,1 +1,1 @@
-bash tools/final_profile.sh r02_mid 2>&1 | tail -15
+bash tools/final_profile.sh r02_final 2>&1 | tail -14
