@@ -1,1 +1,2 @@
-bash tools/final_profile.sh r02_final 2>&1 | tail -14
+mkdir -p gpurun_out/r2r
+timeout -k 10 120 ./tools/probes/gather_probe > gpurun_out/r2r/gather.txt 2>&1; cat gpurun_out/r2r/gather.txt
