@@ -286,7 +286,7 @@ struct Collapser {
 
 static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int budget0, FastBvh& out);
 
-void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out)
+void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out, int stack_limit)
 {
     out = FastBvh();
     if (const char* e = std::getenv("MCPT_FAST_LEAF")) kMaxLeafRt = std::max(1, std::min(kFastMaxLeaf, std::atoi(e)));
@@ -306,19 +306,21 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
         }
     }
     out.scene_absmax = amax;
-    build_from_boxes(prim, kMaxLeafRt, kFastMaxDepth - 1, out);
+    build_from_boxes(prim, kMaxLeafRt, stack_limit - 1, out);
+    out.stack_limit = stack_limit;
 }
 
 // Upper part of a two-part hierarchy (MCPT_BUILD_DEVICE_FAST): the SAH tree over the boxes of clusters the GPU has built, one
 // cluster per leaf.  lower_need = traversal stack entries a cluster's own subtree needs.  A leaf child of out.cw comes back as
 // -1 - cluster; the caller turns it into the index of that cluster's root node.
-void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out)
+void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out, int stack_limit)
 {
     out = FastBvh();
     std::vector<Box> prim(static_cast<size_t>(n), Box{});
     for (int i = 0; i < n; i++)
         for (int a = 0; a < 3; a++) { prim[size_t(i)].lo[a] = boxes6[size_t(i) * 6 + a]; prim[size_t(i)].hi[a] = boxes6[size_t(i) * 6 + 3 + a]; }
-    build_from_boxes(prim, 1, kFastMaxDepth - 1 - lower_need, out);
+    build_from_boxes(prim, 1, stack_limit - 1 - lower_need, out);
+    out.stack_limit = stack_limit;
     for (CwNode& nd : out.cw)
         for (int c = 0; c < 4; c++)
             if (nd.child[c] < 0 && nd.child[c] != kFastEmpty) nd.child[c] = -1 - out.leaf_tris[size_t((-1 - nd.child[c]) >> 4)];

@@ -11,7 +11,12 @@ namespace mcpt {
 #ifndef MCPT_FAST_STACK
 #define MCPT_FAST_STACK 36
 #endif
-constexpr int kFastMaxDepth = MCPT_FAST_STACK;          // inner levels; bounds the per-lane LDS stack
+constexpr int kFastMaxDepth = MCPT_FAST_STACK;          // inner levels; bounds the per-lane LDS stack of the deep-stack kernels
+// The trace engine exists in two shapes (wavefront.hip): a 27-entry stack leaves LDS and registers for 4 waves per SIMD, the 36-entry
+// one for 3.  A hierarchy built for the short stack is a little worse on small scenes (cornell-box: 6.9 instead of 6.8 node visits per
+// ray, which the fourth wave repays several times) and much worse on very large ones (10 M triangles: 67 instead of 44), hence:
+constexpr int kFastShortStack = 27;
+constexpr int kFastShortStackMaxTris = 1 << 20;
 constexpr int kFastMaxLeaf = 4;            // most triangles a leaf may hold (3 bits of the reference; bit 3 is a runtime flag)
 constexpr int kFastDefaultLeaf = 4;        // default leaf size (measured: 4 beats 1 and 2 on MI355X; inner steps cost more than leaf boxes)
 constexpr int32_t kFastEmpty = INT32_MIN;  // child reference of an absent child
@@ -19,6 +24,7 @@ constexpr int32_t kFastEmpty = INT32_MIN;  // child reference of an absent child
 struct FastBvh {
     std::vector<CwNode> cw;                // compressed 4-wide collapse of `nodes` (what the kernels walk)
     int cw_stack_need = 0;                 // worst-case traversal stack entries
+    int stack_limit = kFastMaxDepth;       // what it was built to stay below
     std::vector<FastNode> nodes;
     std::vector<int32_t> leaf_tris;        // reference leaf index k of every slot of the leaf triangle list
     double scene_absmax = 0;               // largest |coordinate| of any leaf box
@@ -26,8 +32,8 @@ struct FastBvh {
 };
 
 // order[k] = .obj face held by reference leaf k
-void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out);
+void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out, int stack_limit = kFastMaxDepth);
 // upper part over n GPU-built clusters given by their boxes (lo[3], hi[3]); see accel_build.cpp
-void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out);
+void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out, int stack_limit = kFastMaxDepth);
 
 }  // namespace mcpt

@@ -71,12 +71,21 @@ struct mcpt_scene {
     mutable std::vector<int32_t> fast_order;
 };
 
+// Small scenes get a hierarchy that fits the short traversal stack (4 waves per SIMD in the trace kernels), large ones the deep one
+// (accel_build.hpp).  MCPT_FAST_STACK_LIMIT overrides (tests, A/B runs).
+static int stack_limit_for(size_t triangles)
+{
+    if (const char* e = std::getenv("MCPT_FAST_STACK_LIMIT")) { const int v = std::atoi(e); if (v >= 8 && v <= kFastMaxDepth) return v; }
+    return triangles <= size_t(kFastShortStackMaxTris) ? kFastShortStack : kFastMaxDepth;
+}
+
 static std::shared_ptr<const FastBvh> shared_fast_bvh(const mcpt_scene* h, const std::vector<int32_t>& order)
 {
     std::lock_guard<std::mutex> lock(h->fast_mu);
-    if (!h->fast_cached || h->fast_order != order) {
+    const int limit = stack_limit_for(h->s.faces.size());
+    if (!h->fast_cached || h->fast_order != order || h->fast_cached->stack_limit != limit) {
         auto fb = std::make_shared<FastBvh>();
-        build_fast_bvh(h->s.faces, order.data(), int(h->s.faces.size()), *fb);
+        build_fast_bvh(h->s.faces, order.data(), int(h->s.faces.size()), *fb, limit);
         h->fast_cached = fb;
         h->fast_order = order;
     }
@@ -675,7 +684,10 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
     S.area0 = s.area0;
     S.fast.cw = d->cw_nodes; S.fast.nodes = nullptr; S.fast.tris = d->fast_tris; S.fast.absmax = fb_ro.scene_absmax;
-    S.fast.enabled = (coords_ok && fb_ro.max_depth < kFastMaxDepth && fb_ro.cw_stack_need < kFastMaxDepth && fb_ro.scene_absmax >= 1e-15 &&
+    // (the one-lane walks of the finishing and deferred-ray kernels always have the deep stack; the engine's stack is the limit the
+    // hierarchy was built for)
+    S.fast.stack_limit = fast_on_device ? kFastMaxDepth : fb_ro.stack_limit;
+    S.fast.enabled = (coords_ok && fb_ro.max_depth < kFastMaxDepth && fb_ro.cw_stack_need < S.fast.stack_limit && fb_ro.scene_absmax >= 1e-15 &&
                       fb_ro.scene_absmax <= 1e15) ? 1 : 0;
     const CameraFrame cf = camera_frame(s);
     S.cam.eye[0] = cf.eye.x; S.cam.eye[1] = cf.eye.y; S.cam.eye[2] = cf.eye.z;

@@ -62,7 +62,7 @@ struct DFast {
     const DTri* tris;          // DTri records permuted into fast-leaf order (leaf field = reference leaf index)
     double absmax;             // largest |coordinate| in the scene
     int32_t enabled;           // 0: scene has coordinates outside [1e-150,1e150] -> reference-shaped walk only
-    int32_t pad;
+    int32_t stack_limit;       // stack entries the hierarchy was built to stay below: picks the short-stack or the deep-stack trace kernels
 };
 
 struct alignas(16) DMaterial {

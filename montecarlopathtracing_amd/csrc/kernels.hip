@@ -6,6 +6,7 @@
 // No MFMA: this is per-lane tree walking and branching, not a contraction.  wave64 throughout.
 #include <hip/hip_runtime.h>
 
+#include "accel_build.hpp"
 #include "dev_common.hpp"
 #include "kernels.hpp"
 #include "shade_common.hpp"
@@ -69,21 +70,21 @@ struct PrimaryRaySource {
     }
 };
 
-template <class Src>
-__global__ void __launch_bounds__(256, 3) k_trace_persistent(DScene S, Src src, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
-                                                          long long chunk, DCounters* ctr)
+template <class Src, int STACK, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_trace_persistent(DScene S, Src src, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
+                                                                long long chunk, DCounters* ctr)
 {
-    __shared__ int lds_stack[MCPT_FAST_STACK * 256];
+    __shared__ int lds_stack[STACK * 256];
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
     LaneStats ls;
     Work w = {0, 0};
 #if MCPT_POP_CULL
-    __shared__ unsigned short lds_keys[MCPT_FAST_STACK * 256];
+    __shared__ unsigned short lds_keys[STACK * 256];
     unsigned short* keys = lds_keys + threadIdx.x;
 #else
     unsigned short* keys = nullptr;
 #endif
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys, STACK);
     ls.nodes = w.nodes; ls.tris = w.tris;
     flush_stats(ctr, ls);
 }
@@ -92,9 +93,10 @@ template <class Src>
 __global__ void __launch_bounds__(256) k_trace_slow(DScene S, Src src, const TraceQueue* queue, const long long* slow_list, unsigned int slow_cap,
                                                     DCounters* ctr)
 {
+    __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     LaneStats ls;
     Work w = {0, 0};
-    trace_slow_list(S, src, queue, slow_list, slow_cap, w);
+    trace_slow_list(S, src, queue, slow_list, slow_cap, w, lds_stack + threadIdx.x);
     ls.nodes = w.nodes; ls.tris = w.tris;
     flush_stats(ctr, ls);
 }
@@ -237,19 +239,24 @@ static inline unsigned blocks_for(long long n, int block) { return (unsigned)((n
 
 template <class Src>
 static void launch_persistent(const DScene& S, const Src& src, long long total, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
-                              DCounters* ctr, hipStream_t st, int grid)
+                              DCounters* ctr, hipStream_t st, int grid, int grid_short)
 {
+    const bool shallow = S.fast.stack_limit <= kFastShortStack;
+    const int resident = shallow ? grid_short : grid;
     const long long blocks_needed = (total + 255) / 256;
-    const int g = (int)(blocks_needed < grid ? blocks_needed : grid);
+    const int g = (int)(blocks_needed < resident ? blocks_needed : resident);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    hipLaunchKernelGGL(k_trace_persistent<Src>, dim3(g), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, persistent_chunk(total, g), ctr);
+    if (shallow) hipLaunchKernelGGL((k_trace_persistent<Src, kFastShortStack, 4>), dim3(g), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, persistent_chunk(total, g), ctr);
+    else hipLaunchKernelGGL((k_trace_persistent<Src, MCPT_FAST_STACK, 3>), dim3(g), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, persistent_chunk(total, g), ctr);
     hipLaunchKernelGGL(k_trace_slow<Src>, dim3(256), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, ctr);
 }
 
 void init_launch_cfg_closest(LaunchCfg& cfg)
 {
-    cfg.array_grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<ArrayRaySource>), cfg.cus);
-    cfg.primary_grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<PrimaryRaySource>), cfg.cus);
+    cfg.array_grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<ArrayRaySource, MCPT_FAST_STACK, 3>), cfg.cus);
+    cfg.primary_grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<PrimaryRaySource, MCPT_FAST_STACK, 3>), cfg.cus);
+    cfg.array_grid_short = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<ArrayRaySource, kFastShortStack, 4>), cfg.cus);
+    cfg.primary_grid_short = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<PrimaryRaySource, kFastShortStack, 4>), cfg.cus);
 }
 
 // d_face, d_t, d_p must be non-null device buffers (the C-ABI layer always allocates them); d_pn may be null
@@ -263,7 +270,7 @@ void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long
         return;
     }
     ArrayRaySource src; src.rays = d_rays; src.n = n; src.leaf_out = d_face; src.t_out = d_t; src.p_out = d_p;
-    launch_persistent(S, src, n, queue, slow_list, slow_cap, ctr, st, cfg.array_grid);
+    launch_persistent(S, src, n, queue, slow_list, slow_cap, ctr, st, cfg.array_grid, cfg.array_grid_short);
     hipLaunchKernelGGL(k_finish_hits, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, n, d_face, d_p, d_pn, ctr);
 }
 void launch_pack_pixels(const double* d_frame, const int32_t* d_pixels, long long n_pixels, double* d_out, hipStream_t st)
@@ -290,7 +297,7 @@ void launch_primary_hits(const DScene& S, bool fast, const double* d_dirs, const
     }
     PrimaryRaySource src; src.dirs = d_dirs; src.pixels = d_pixels; src.n_pixels = n_pixels; src.hits = d_hits;
     src.eye[0] = S.cam.eye[0]; src.eye[1] = S.cam.eye[1]; src.eye[2] = S.cam.eye[2];
-    launch_persistent(S, src, n_pixels, queue, slow_list, slow_cap, ctr, st, cfg.primary_grid);
+    launch_persistent(S, src, n_pixels, queue, slow_list, slow_cap, ctr, st, cfg.primary_grid, cfg.primary_grid_short);
 }
 void launch_shade_samples(const DScene& S, unsigned long long seed, const double* d_dirs, const int32_t* d_pixels,
                           const PrimaryHit* d_hits, int first_slot, int n_slots, int spp, double* d_rad, DCounters* ctr, hipStream_t st)

@@ -22,8 +22,9 @@ struct TraceQueue;
 struct LaunchCfg {
     int cus = 0;
     unsigned logic_first = 0, logic_rest = 0;       // k_wf_logic<true> / <false>
-    int trace_grid = 0, finish_grid = 0;            // k_wf_trace, k_wf_finish
-    int array_grid = 0, primary_grid = 0;           // k_trace_persistent<ArrayRaySource> / <PrimaryRaySource>
+    int trace_grid = 0, trace_grid_short = 0, finish_grid = 0;   // k_wf_trace (deep / short stack), k_wf_finish
+    int array_grid = 0, primary_grid = 0;           // k_trace_persistent<ArrayRaySource> / <PrimaryRaySource>, deep stack
+    int array_grid_short = 0, primary_grid_short = 0;   // ... short stack
     long long trace_block_rays = 2048;              // MCPT_TRACE_BLOCK_RAYS: a block of k_wf_trace is started per this many rays
     int min_chunk = 256, max_chunk = 2048;          // MCPT_TRACE_MIN_CHUNK / MAX_CHUNK: ray slots per queue claim
 };

@@ -38,6 +38,11 @@ namespace mcpt {
 #ifndef MCPT_INNER_BURST
 #define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
 #endif
+#ifndef MCPT_SLIM_STATE
+#define MCPT_SLIM_STATE 1           /* 1: a register diet for a fourth wave per SIMD -- the next 64 slots are fetched when the LDS batch runs
+                                       out (not a batch ahead, in registers), and of 1/d only the x component is kept (the other two are
+                                       recomputed where a ray is finished) */
+#endif
 #ifndef MCPT_TRI_SHARE
 #define MCPT_TRI_SHARE 0            /* 1: the triangle phase hands the pending (ray, triangle) pairs of all its lanes out to all 64 lanes
                                        (a lane with a 4-triangle leaf gets three helpers) instead of every lane walking its own leaf one
@@ -51,7 +56,10 @@ namespace mcpt {
                                        dropped instead of visited */
 #endif
 #ifndef MCPT_INBAND_INPLACE
-#define MCPT_INBAND_INPLACE 1       /* 0: a ray with two candidates the products cannot rank goes to the exact walk instead */
+#define MCPT_INBAND_INPLACE 0       /* how two candidates the products cannot rank are told apart: 1 = by the reference's own t_k and leaf index on
+                                       the spot; 2 = the contender is remembered and the two are ranked where the ray is finished (fewer
+                                       registers in the triangle phase; a second contender sends the ray to the exact walk); 0 = the ray
+                                       goes to the exact walk */
 #endif
 #ifndef MCPT_LAZY_VERIFY
 #define MCPT_LAZY_VERIFY 1          /* 1: a triangle whose test passes only has the RANK of its distance looked at (two multiplies);
@@ -69,13 +77,18 @@ namespace mcpt {
 //   stage 2: when the LDS batch is used up, stage 1 is written to LDS ([component][lane], 52 B per ray) and the following
 //            64 slots are requested at once; idle lanes take entries of the LDS batch by ballot rank.
 #define MCPT_RAYBUF_DOUBLES 6
+#if MCPT_TRI_SHARE
 #define MCPT_RAYBUF_BYTES (64 * (MCPT_RAYBUF_DOUBLES * 8 + 4 + 4))  /* per wave: 64 rays, their flags, and the owner table of MCPT_TRI_SHARE */
+#else
+#define MCPT_RAYBUF_BYTES (64 * (MCPT_RAYBUF_DOUBLES * 8 + 4))      /* per wave: 64 rays and their flags */
+#endif
 
 template <class Src>
 __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src, TraceQueue* queue, long long* __restrict__ slow_list,
                                                  unsigned int slow_cap, long long chunk, int* __restrict__ stack, int stride,
                                                  double* __restrict__ raybuf /* this wave's MCPT_RAYBUF_BYTES of LDS */, Work& w,
-                                                 unsigned short* __restrict__ kstack = nullptr /* MCPT_POP_CULL: [depth][lane] like stack */)
+                                                 unsigned short* __restrict__ kstack = nullptr /* MCPT_POP_CULL: [depth][lane] like stack */,
+                                                 int stack_cap = MCPT_FAST_STACK /* entries of `stack` per lane */)
 {
     const DFast& F = S.fast;
     const CwNode* __restrict__ nodes = F.cw;
@@ -95,15 +108,25 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     bool queue_empty = false;                   // no more slots anywhere
     long long reg_base = 0; int reg_count = 0;  // stage 1: slots [reg_base, reg_base+reg_count) in flight / in registers
     long long lds_base = 0; int lds_count = 0, lds_taken = 0;   // stage 2
+#if !MCPT_SLIM_STATE
     Ray reg_ray; reg_ray.o = mk(0, 0, 0); reg_ray.d = mk(1, 1, 1);
     bool reg_valid = false;
+#endif
 
     // lane state
     enum { ST_IDLE = 0, ST_INNER = 1, ST_TRI = 2 };
     int state = ST_IDLE;
     long long slot = -1;
     Ray r; r.o = mk(0, 0, 0); r.d = mk(1, 1, 1);
+#if MCPT_SLIM_STATE
+    double rcp_x = 1;
+#define MCPT_RCP_X rcp_x
+#define MCPT_FULL_RCP() mk(rcp_x, fast_rcp(r.d.y), fast_rcp(r.d.z))
+#else
     V3 rcp = mk(1, 1, 1);
+#define MCPT_RCP_X rcp.x
+#define MCPT_FULL_RCP() rcp
+#endif
     RayF rf; for (int a = 0; a < 3; a++) { rf.o[a] = 0; rf.r[a] = 1; rf.pad[a] = 0; }
     float limit_f = 0;
     double margin = 0, limit = 0;
@@ -113,6 +136,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     // best.t holds the product (p.x - o.x) * (1 / d.x) of the leading candidate (within 2^-50 of its t_k), best.leaf its slot in
     // the fast triangle array; the candidate is verified (own box) and t_k divided out in finish_ray().
     bool ambiguous = false;             // two candidates closer than the products can tell apart: the ray goes to the exact walk
+#if MCPT_INBAND_INPLACE == 2
+    int alt = -1;                       // a contender within the products' resolution of the leader (slot in the fast triangle array)
+#endif
     bool solo = false;                  // MCPT_TRI_SHARE: this lane walks the rest of its leaf itself (a near-tie needs the exact comparison)
     (void)solo;
 #endif
@@ -126,10 +152,22 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         // resolution of the products; otherwise the ray is re-walked exactly (reference-shaped walk, second launch).
         Hit h; h.leaf = -1; h.t = 0; h.p = best.p;
         if (found) {
+            const V3 rc = MCPT_FULL_RCP();
             const DTri* tr = tris + best.leaf;
-            if (!own_box_hit(tr, r, rcp)) ambiguous = true;
+            if (!own_box_hit(tr, r, rc)) ambiguous = true;
             h.leaf = tr->leaf;
             h.t = (best.p.x - r.o.x) / r.d.x;                   // pathTracing.cpp:347
+#if MCPT_INBAND_INPLACE == 2
+            if (alt >= 0 && !ambiguous) {
+                // the contender: its hit point again (the same arithmetic gives the same bits), its own box, then the reference's order
+                const DTri* ta_ = tris + alt;
+                V3 pa;
+                if (tri_hit(ta_, r, pa) && own_box_hit(ta_, r, rc)) {
+                    const double t_alt = (pa.x - r.o.x) / r.d.x;
+                    if (t_alt > 0 && (t_alt < h.t || (t_alt == h.t && ta_->leaf < h.leaf))) { h.leaf = ta_->leaf; h.t = t_alt; h.p = pa; }
+                }
+            }
+#endif
         }
         if (ambiguous) {
             const unsigned int at = atomicAdd(&queue->slow_count, 1u);
@@ -159,7 +197,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         reg_count = avail < 64 ? (int)avail : 64;
         reg_base = next;
         next += reg_count;
+#if !MCPT_SLIM_STATE
         reg_valid = lane < reg_count && src.fetch(reg_base + lane, reg_ray);
+#endif
     };
     request();
 
@@ -184,6 +224,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                 if (!idle) break;
                 if (lds_taken >= lds_count) {            // stage 1 -> stage 2, and ask for the batch after it
                     if (reg_count == 0) break;           // nothing left anywhere
+#if MCPT_SLIM_STATE
+                    Ray reg_ray; reg_ray.o = mk(0, 0, 0); reg_ray.d = mk(1, 1, 1);
+                    const bool reg_valid = lane < reg_count && src.fetch(reg_base + lane, reg_ray);
+#endif
                     raybuf[0 * 64 + lane] = reg_ray.o.x; raybuf[1 * 64 + lane] = reg_ray.o.y; raybuf[2 * 64 + lane] = reg_ray.o.z;
                     raybuf[3 * 64 + lane] = reg_ray.d.x; raybuf[4 * 64 + lane] = reg_ray.d.y; raybuf[5 * 64 + lane] = reg_ray.d.z;
                     rayflag[lane] = reg_valid ? 1 : 0;
@@ -204,7 +248,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                         if (fast_path_ok(F, nr)) {
                             w.rays++;
                             slot = q; r = nr;
+#if MCPT_SLIM_STATE
+                            const V3 rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+                            rcp_x = rcp.x;
+#else
                             rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+#endif
                             const double rmax = fmax(fmax(fabs(rcp.x), fabs(rcp.y)), fabs(rcp.z));     // = 1 / min|d_k|
                             const double scale = fmax(fmax(F.absmax, fabs(r.o.x)), fmax(fabs(r.o.y), fabs(r.o.z)));
                             margin = rmax <= 1e6 ? 1.0000001e-9 * scale * rmax : __builtin_inf();
@@ -213,6 +262,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                             found = false; best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
 #if MCPT_LAZY_VERIFY
                             ambiguous = false;
+#if MCPT_INBAND_INPLACE == 2
+                            alt = -1;
+#endif
 #endif
                             sp = 0; cur = 0; state = ST_INNER;
                         } else {
@@ -246,8 +298,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
             for (int burst = 0; burst < MCPT_INNER_BURST; burst++)
             if (state == ST_INNER) {
 #if MCPT_LAZY_VERIFY
-                // three pushes must fit: a ray whose stack would overflow (deeper than this build's MCPT_FAST_STACK) goes to the exact walk
-                if (sp > MCPT_FAST_STACK - 3) { ambiguous = true; state = ST_IDLE; }
+                // three pushes must fit: a ray whose stack would overflow (the hierarchy is built not to need that) goes to the exact walk
+                if (sp > stack_cap - 3) { ambiguous = true; state = ST_IDLE; }
                 else {
 #else
                 {
@@ -294,10 +346,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
 #if MCPT_LAZY_VERIFY
                     // t_k = (p.x - o.x) / d.x is within 2^-50 (relative) of this product and has its sign: two candidates whose
                     // products differ by more than 2^-47 are ranked like their t_k
-                    const double ta = (p.x - r.o.x) * rcp.x;
+                    const double ta = (p.x - r.o.x) * MCPT_RCP_X;
                     if (ta > 0.0) {
                         const double band = best.t * 0x1p-47;
                         if (!found || ta < best.t - band) {
+#if MCPT_INBAND_INPLACE == 2
+                            // a remembered contender lies within one band of the old leader: it stays clearly behind the new leader
+                            // only if that one leads by more than four bands
+                            if (found && alt >= 0) { if (ta < best.t - 4.0 * band) alt = -1; else ambiguous = true; }
+#endif
                             found = true; best.leaf = tri_i - 1; best.t = ta; best.p = p;
                             limit = (ta + ta * 0x1p-47) + margin;
                             limit_f = __double2float_ru(limit);
@@ -307,8 +364,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                             // at all.  The leader's own box is looked at when the ray is finished, like any leader's.
 #if !MCPT_INBAND_INPLACE
                             ambiguous = true;
+#elif MCPT_INBAND_INPLACE == 2
+                            if (alt < 0) alt = tri_i - 1; else ambiguous = true;
 #else
-                            if (own_box_hit(tr, r, rcp)) {
+                            if (own_box_hit(tr, r, MCPT_FULL_RCP())) {
                                 const double t_new = (p.x - r.o.x) / r.d.x, t_old = (best.p.x - r.o.x) / r.d.x;
                                 if (t_new < t_old || (t_new == t_old && tr->leaf < tris[best.leaf].leaf)) {
                                     best.leaf = tri_i - 1; best.t = ta; best.p = p;
@@ -346,7 +405,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                 Ray hr;
                 hr.o = mk(__shfl(r.o.x, ow, 64), __shfl(r.o.y, ow, 64), __shfl(r.o.z, ow, 64));
                 hr.d = mk(__shfl(r.d.x, ow, 64), __shfl(r.d.y, ow, 64), __shfl(r.d.z, ow, 64));
-                const double h_rcpx = __shfl(rcp.x, ow, 64), h_best = __shfl(best.t, ow, 64);
+                const double h_rcpx = __shfl(MCPT_RCP_X, ow, 64), h_best = __shfl(best.t, ow, 64);
                 const int h_found = __shfl((int)found, ow, 64);
                 const int h_tri = __shfl(tri_i, ow, 64) + kk;
                 V3 hp = mk(0, 0, 0);
@@ -422,9 +481,19 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
 
 // second pass: the deferred rays, one lane each, reference-shaped walk.  If more rays were deferred than the side list
 // holds (pathological input), every slot is scanned and the rays that failed fast_path_ok() are recognised again.
+// A deferred ray is either one the fast walk may not take at all (fast_path_ok fails: reference-shaped walk) or one whose candidates
+// the engine could not rank from products alone (a near-tie, a stack overflow): that one is walked again on the fast hierarchy, one
+// lane per ray, with every candidate decided exactly on the spot (trace_lane_fast) -- a few times the cost of an ordinary ray, where
+// the exhaustive walk costs ~1 300 node visits.  stack: this lane's LDS words (stride 256), or nullptr (then always the exhaustive walk).
+__device__ __forceinline__ bool trace_deferred(const DScene& S, const Ray& r, Hit& h, Work& w, int* __restrict__ stack)
+{
+    if (stack && fast_path_ok(S.fast, r)) return trace_lane_fast(S, r, h, w, stack, 256);
+    return trace_closest(S, r, h, w);
+}
+
 template <class Src>
 __device__ __forceinline__ void trace_slow_list(const DScene& S, const Src& src, const TraceQueue* queue, const long long* __restrict__ slow_list,
-                                                unsigned int slow_cap, Work& w)
+                                                unsigned int slow_cap, Work& w, int* __restrict__ stack = nullptr)
 {
     const unsigned int n = queue->slow_count;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -435,7 +504,7 @@ __device__ __forceinline__ void trace_slow_list(const DScene& S, const Src& src,
             Ray r;
             if (!src.fetch(q, r)) continue;
             Hit h;
-            const bool ok = trace_closest(S, r, h, w);
+            const bool ok = trace_deferred(S, r, h, w, stack);
             src.store(q, ok, h);
         }
     } else {
@@ -445,7 +514,7 @@ __device__ __forceinline__ void trace_slow_list(const DScene& S, const Src& src,
             Ray r;
             if (!src.fetch(q, r) || (!redo_all && fast_path_ok(S.fast, r))) continue;
             Hit h;
-            const bool ok = trace_closest(S, r, h, w);
+            const bool ok = trace_deferred(S, r, h, w, stack);
             src.store(q, ok, h);
         }
     }

@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 
+#include "accel_build.hpp"
 #include "dev_common.hpp"
 #include "shade_common.hpp"
 #include "trace_persistent.hpp"
@@ -255,18 +256,18 @@ __device__ __forceinline__ long long wf_chunk(long long total, int min_chunk, in
     return c < min_chunk ? min_chunk : (c > max_chunk ? max_chunk : c);
 }
 
-#ifndef MCPT_TRACE_WAVES
-#define MCPT_TRACE_WAVES 3   /* waves per SIMD: 168 VGPRs, 45 KB of LDS per block */
-#endif
-__global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, int min_chunk, int max_chunk)
+// Two shapes of the kernel: SHORT = a kFastShortStack-entry stack (27 KB of LDS per block, 128 VGPRs: 4 waves per SIMD) for hierarchies
+// built to fit it, else MCPT_FAST_STACK entries at 3 waves per SIMD (accel_build.hpp).
+template <int STACK, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_wf_trace(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, int min_chunk, int max_chunk)
 {
     const long long n_paths = a.counts->n_next;
     if (n_paths <= (long long)a.finish_below) return;                  // nothing left, or k_wf_finish has taken the paths
     const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk, max_chunk);
-    __shared__ int lds_stack[MCPT_FAST_STACK * 256];
+    __shared__ int lds_stack[STACK * 256];
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
 #if MCPT_POP_CULL
-    __shared__ unsigned short lds_keys[MCPT_FAST_STACK * 256];
+    __shared__ unsigned short lds_keys[STACK * 256];
     unsigned short* keys = lds_keys + threadIdx.x;
 #else
     unsigned short* keys = nullptr;
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(256, MCPT_TRACE_WAVES) k_wf_trace(DScene S, Wf
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys, STACK);
     ls.nodes = w.nodes; ls.tris = w.tris;
     if (a.ctr) {        // the dominant kernel's own work, for its roofline
         const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays);
@@ -291,10 +292,11 @@ __global__ void __launch_bounds__(256) k_wf_trace_slow(DScene S, WfArgs a, const
     const long long n_paths = a.counts->n_next;
     if (n_paths <= (long long)a.finish_below || queue->slow_count == 0) return;
     if (a.ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.ctr->pad[12], (unsigned long long)queue->slow_count);   // diagnostics
+    __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
-    trace_slow_list(S, src, queue, slow_list, slow_cap, w);
+    trace_slow_list(S, src, queue, slow_list, slow_cap, w, lds_stack + threadIdx.x);
     ls.nodes = w.nodes; ls.tris = w.tris;
     flush_stats(a.ctr, ls);
 }
@@ -569,7 +571,8 @@ void init_launch_cfg(LaunchCfg& cfg)
     const unsigned forced = e ? unsigned(std::atoi(e)) : 0u;
     cfg.logic_first = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<true>), cfg.cus));
     cfg.logic_rest = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<false>), cfg.cus));
-    cfg.trace_grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace), cfg.cus);
+    cfg.trace_grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace<MCPT_FAST_STACK, 3>), cfg.cus);
+    cfg.trace_grid_short = persistent_grid(reinterpret_cast<const void*>(k_wf_trace<kFastShortStack, 4>), cfg.cus);
     cfg.finish_grid = persistent_grid(reinterpret_cast<const void*>(k_wf_finish), cfg.cus);
     // a wave that starts pays one atomic on the queue head and a few on the counters: give every block >= 2048 rays
     e = std::getenv("MCPT_TRACE_BLOCK_RAYS");
@@ -606,11 +609,14 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
         hipLaunchKernelGGL(k_wf_trace_reference, dim3(grid_for(total, 256, 1u << 20)), dim3(256), 0, st, S, a);
         return;
     }
+    const bool shallow = S.fast.stack_limit <= kFastShortStack;
+    const int resident = shallow ? cfg.trace_grid_short : cfg.trace_grid;
     const long long blocks_needed = (total + cfg.trace_block_rays - 1) / cfg.trace_block_rays;
-    const int g = (int)(blocks_needed < cfg.trace_grid ? blocks_needed : cfg.trace_grid);
+    const int g = (int)(blocks_needed < resident ? blocks_needed : resident);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    hipLaunchKernelGGL(k_wf_trace, dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
-    hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 64 ? g : 64), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);
+    if (shallow) hipLaunchKernelGGL((k_wf_trace<kFastShortStack, 4>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
+    else hipLaunchKernelGGL((k_wf_trace<MCPT_FAST_STACK, 3>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
+    hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 512 ? g : 512), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);   // (blocks without work leave at once)
 }
 
 void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st, const LaunchCfg& cfg)
