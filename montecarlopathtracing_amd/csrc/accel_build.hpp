@@ -13,10 +13,8 @@ namespace mcpt {
 #endif
 constexpr int kFastMaxDepth = MCPT_FAST_STACK;          // inner levels; bounds the per-lane LDS stack of the deep-stack kernels
 // The trace engine exists in two shapes (wavefront.hip): a 27-entry stack leaves LDS and registers for 4 waves per SIMD, the 36-entry
-// one for 3.  A hierarchy built for the short stack is a little worse on small scenes (cornell-box: 6.9 instead of 6.8 node visits per
-// ray, which the fourth wave repays several times) and much worse on very large ones (10 M triangles: 67 instead of 44), hence:
+// one for 3.  Hierarchies are built for the deep stack; the short-stack engine hands a ray that would overflow to the one-lane walk.
 constexpr int kFastShortStack = 27;
-constexpr int kFastShortStackMaxTris = 1 << 20;
 constexpr int kFastMaxLeaf = 4;            // most triangles a leaf may hold (3 bits of the reference; bit 3 is a runtime flag)
 constexpr int kFastDefaultLeaf = 4;        // default leaf size (measured: 4 beats 1 and 2 on MI355X; inner steps cost more than leaf boxes)
 constexpr int32_t kFastEmpty = INT32_MIN;  // child reference of an absent child

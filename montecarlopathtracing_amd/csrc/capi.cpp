@@ -71,12 +71,11 @@ struct mcpt_scene {
     mutable std::vector<int32_t> fast_order;
 };
 
-// Small scenes get a hierarchy that fits the short traversal stack (4 waves per SIMD in the trace kernels), large ones the deep one
-// (accel_build.hpp).  MCPT_FAST_STACK_LIMIT overrides (tests, A/B runs).
-static int stack_limit_for(size_t triangles)
+// The hierarchy is always built for the deep stack (the better tree); MCPT_FAST_STACK_LIMIT builds it for a shallower one (A/B runs).
+static int stack_limit_for(size_t)
 {
     if (const char* e = std::getenv("MCPT_FAST_STACK_LIMIT")) { const int v = std::atoi(e); if (v >= 8 && v <= kFastMaxDepth) return v; }
-    return triangles <= size_t(kFastShortStackMaxTris) ? kFastShortStack : kFastMaxDepth;
+    return kFastMaxDepth;
 }
 
 static std::shared_ptr<const FastBvh> shared_fast_bvh(const mcpt_scene* h, const std::vector<int32_t>& order)
@@ -684,11 +683,16 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
     S.area0 = s.area0;
     S.fast.cw = d->cw_nodes; S.fast.nodes = nullptr; S.fast.tris = d->fast_tris; S.fast.absmax = fb_ro.scene_absmax;
-    // (the one-lane walks of the finishing and deferred-ray kernels always have the deep stack; the engine's stack is the limit the
-    // hierarchy was built for)
-    S.fast.stack_limit = fast_on_device ? kFastMaxDepth : fb_ro.stack_limit;
-    S.fast.enabled = (coords_ok && fb_ro.max_depth < kFastMaxDepth && fb_ro.cw_stack_need < S.fast.stack_limit && fb_ro.scene_absmax >= 1e-15 &&
+    S.fast.enabled = (coords_ok && fb_ro.max_depth < kFastMaxDepth && fb_ro.cw_stack_need < kFastMaxDepth && fb_ro.scene_absmax >= 1e-15 &&
                       fb_ro.scene_absmax <= 1e15) ? 1 : 0;
+    // Which shape of the trace engine walks it (wavefront.hip): by default the short-stack one at 4 waves per SIMD -- the hierarchy may
+    // need up to kFastMaxDepth - 1 entries in the worst case, but a ray that would push past entry 27 is simply handed to the one-lane
+    // walk (deep stack), and on every scene measured none does (10 M triangles: 0 of 1.5e8 rays).  MCPT_SHORT_KERNEL=0: the deep-stack
+    // engine at 3 waves per SIMD.
+    S.fast.stack_limit = kFastShortStack;
+    if (const char* e = std::getenv("MCPT_SHORT_KERNEL")) if (std::atoi(e) == 0) S.fast.stack_limit = kFastMaxDepth;
+    S.fast.stack_cap = S.fast.stack_limit;
+    if (const char* e = std::getenv("MCPT_TEST_STACK_CAP")) { const int v = std::atoi(e); if (v >= 4 && v < S.fast.stack_cap) S.fast.stack_cap = v; }
     const CameraFrame cf = camera_frame(s);
     S.cam.eye[0] = cf.eye.x; S.cam.eye[1] = cf.eye.y; S.cam.eye[2] = cf.eye.z;
     S.cam.start_point[0] = cf.start_point.x; S.cam.start_point[1] = cf.start_point.y; S.cam.start_point[2] = cf.start_point.z;

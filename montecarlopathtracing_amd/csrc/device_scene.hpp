@@ -62,7 +62,9 @@ struct DFast {
     const DTri* tris;          // DTri records permuted into fast-leaf order (leaf field = reference leaf index)
     double absmax;             // largest |coordinate| in the scene
     int32_t enabled;           // 0: scene has coordinates outside [1e-150,1e150] -> reference-shaped walk only
-    int32_t stack_limit;       // stack entries the hierarchy was built to stay below: picks the short-stack or the deep-stack trace kernels
+    int32_t stack_limit;       // per-lane stack entries of the trace engine that walks it: picks the short-stack or the deep-stack kernels
+    int32_t stack_cap;         // entries of that stack the engine may use (= stack_limit; tests shrink it to force the overflow hand-over)
+    int32_t pad;
 };
 
 struct alignas(16) DMaterial {

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256, WAVES) k_trace_persistent(DScene S, Src s
 #else
     unsigned short* keys = nullptr;
 #endif
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys, STACK);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
     ls.nodes = w.nodes; ls.tris = w.tris;
     flush_stats(ctr, ls);
 }

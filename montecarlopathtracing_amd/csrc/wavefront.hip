@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_trace(DScene S, WfArgs a, Tra
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys, STACK);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
     ls.nodes = w.nodes; ls.tris = w.tris;
     if (a.ctr) {        // the dominant kernel's own work, for its roofline
         const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays);

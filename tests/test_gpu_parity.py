@@ -129,6 +129,36 @@ def test_deferred_ray_list_overflow(oracle, mcpt, monkeypatch):
     osc.close()
 
 
+def test_stack_overflow_is_handed_to_the_one_lane_walk(oracle, mcpt, monkeypatch):
+    """The trace engine runs with a 27-entry stack per lane (4 waves per SIMD) on a hierarchy that may need up to 35 entries in the
+    worst case; a ray that would push past its stack is handed to the one-lane walk, which has the deep stack.  No ray of the
+    measured scenes does, so the hand-over is forced here: with the engine's stack cut to 6 entries a good share of the rays take
+    it, and closest hits and images stay bit-exact."""
+    monkeypatch.setenv("MCPT_TEST_STACK_CAP", "6")
+    monkeypatch.setenv("MCPT_FINISH_PATHS", "0")
+    osc = oracle.OracleScene(SCENES + "cornell-box", texture_dir=SCENES, width=160, height=90)
+    sc = mcpt.Scene(SCENES, "cornell-box", width=160, height=90)
+    dev = mcpt.Device(sc, 0)
+    rays = make_rays(osc, 40000, seed=19)
+    of, ot, op, opn = osc.trace_closest(rays)
+    gf, gt, gp, gpn = dev.ray_intersect(rays)
+    assert np.array_equal(of, gf)
+    h = of >= 0
+    assert np.array_equal(_bits(ot[h]), _bits(gt[h])) and np.array_equal(_bits(op[h]), _bits(gp[h])) and np.array_equal(_bits(opn[h]), _bits(gpn[h]))
+    st = mcpt.Stats()
+    a = dev.generateImg(8, seed=3, stats=st)
+    b = dev.generateImg(8, seed=3, flags=mcpt.RENDER_MEGAKERNEL)
+    assert np.array_equal(_bits(a), _bits(b))
+    dev.close()
+    monkeypatch.delenv("MCPT_TEST_STACK_CAP")
+    plain = mcpt.Device(sc, 0)
+    st0 = mcpt.Stats()
+    c = plain.generateImg(8, seed=3, stats=st0)
+    assert np.array_equal(_bits(a), _bits(c))
+    assert st.dom_node_visits < 0.8 * st0.dom_node_visits      # the engine really gave rays away (its own node visits dropped)
+    plain.close(); sc.close(); osc.close()
+
+
 def test_sample_radiance(pair, oracle, mcpt):
     name, osc, sc, dev = pair
     rng = np.random.default_rng(5)

@@ -1,14 +1,4 @@
-mkdir -p gpurun_out/r2v
-python -m pytest tests -q -m gpu --durations=5 > gpurun_out/r2v/tests.log 2>&1; rc=$?
-tail -12 gpurun_out/r2v/tests.log | cut -c1-220
-bash tools/_bench_variants.sh gpurun_out/r2v default
-for sc in "synthetic --spp 16" "interior" "veach-mis --spp 100"; do
-    timeout -k 10 300 python bench.py --scene $sc --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r2v/b.json 2> gpurun_out/r2v/b.err || { tail -3 gpurun_out/r2v/b.err; continue; }
-    python -c "
-import json
-d=json.load(open('gpurun_out/r2v/b.json')); print('$sc', 'ms/frame %.2f Mrays/s %.0f nodes/ray %.2f tris/ray %.2f'%(d['ms_per_step'], d['value'], d['nodes_per_ray'], d['tris_per_ray']))"
-done
-timeout -k 10 200 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --sim-world 8 > gpurun_out/r2v/sim8.json 2>/dev/null; python -c "
-import json
-d=json.load(open('gpurun_out/r2v/sim8.json')); print('sim8 ms/frame %.2f'%d['ms_per_step'])"
+mkdir -p gpurun_out/r2x
+python -m pytest tests -q -m gpu --durations=3 > gpurun_out/r2x/tests.log 2>&1; rc=$?
+tail -8 gpurun_out/r2x/tests.log | cut -c1-220
 exit $rc
