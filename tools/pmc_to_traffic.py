@@ -12,7 +12,7 @@ d, kernel, command, out = sys.argv[1:5]
 acc, disp = {}, {}
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"].split("(")[0]
+        name = row["Kernel_Name"].split("(")[0].split("<")[0]        # template arguments off: k_wf_trace<27, 4> is k_wf_trace
         if not name.endswith(kernel):
             continue
         acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
