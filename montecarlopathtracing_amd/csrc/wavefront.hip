@@ -13,8 +13,9 @@
 namespace mcpt {
 
 #ifndef MCPT_LOGIC_WAVES
-#define MCPT_LOGIC_WAVES 3   /* waves per SIMD the logic kernel is compiled for (sweep, ms per frame: 2: 111.5, 3: 108.0, 4: 107.2 but
-                               1 % slower on veach-mis and the interior, 5: 113.5, 6: 121.2) */
+#define MCPT_LOGIC_WAVES 4   /* waves per SIMD the logic kernel is compiled for: 128 VGPRs, 20 / 40 spilled registers.  Round 1 (ms per frame): 2: 111.5,
+                               3: 108.0, 4: 107.2, 5: 113.5, 6: 121.2; with the 4-wave trace engine: 3: 101.6, 4: 100.4 (cornell-box), equal within
+                               0.3 % on veach-mis, the interior and the 10 M-triangle scene */
 #endif
 
 // ---------------------------------------------------------------------------------------------- layout helpers
