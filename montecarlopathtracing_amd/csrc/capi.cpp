@@ -967,7 +967,7 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
         a.first_slot = int(first);
         a.in = A; a.out = B;
         a.counts_in = &f.wf_counts[0];
-        launch_primary_surface(d->ds, a, f.surf, n_slots, st);      // what the samples of a pixel share at their first vertex
+        launch_primary_surface(d->ds, a, f.surf, &f.wf_counts[0].pad[2], n_slots, st);      // what the samples of a pixel share at their first vertex
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < MCPT_MAX_DEPTH && n_upper > 0; depth++) {
             a.depth = depth;

@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
 #else
 #define MCPT_LSTAMP(k)
 #endif
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) a.counts->n_next = a.counts_in->pad[2] * (unsigned int)a.spp;   // shaded pixels x samples
     const long long n_round = (n_prev + 255) / 256 * 256;
     for (long long base = (long long)blockIdx.x * 256; base < n_round; base += (long long)gridDim.x * 256) {
 #ifdef MCPT_TRACE_DIAG
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
 #endif
         const long long i = base + threadIdx.x;
         bool alive = false;
+        long long first_pos = 0;
         int id = 0, leaf = -1, in_type = RT_TRANSMISSION, mat_first = 0, pix_first = 0;
         V3 p = mk(0, 0, 0), dir = mk(0, 0, 0), T = mk(1, 1, 1), L = mk(0, 0, 0), pn_first = mk(0, 0, 0), kd_first = mk(0, 0, 0);
         if (i < n_prev) {
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             if constexpr (FIRST) {
                 const PrimarySurface* ps = a.surf + i / a.spp;          // the same record for all samples of a pixel
                 const int k = (int)(i % a.spp);
+                first_pos = (long long)ps->alive_index * a.spp + k;
                 id = (ps->slot - a.first_slot) * a.spp + k;
                 leaf = ps->leaf; mat_first = ps->material; pix_first = ps->pixel;
                 p = ld3(ps->p); dir = ld3(ps->dir); pn_first = ld3(ps->pn); kd_first = ld3(ps->kd);
@@ -143,7 +146,15 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             if (!alive) { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; }
         }
         MCPT_LSTAMP(0)
-        // ---- compaction: wave ballot + prefix, one atomic per block
+        // ---- compaction.  First pass: none -- a pixel's samples live or die together, so k_primary_surface has numbered the shaded
+        // pixels and sample k of pixel number n sits at n * spp + k (no ballot, no atomic, no barrier).  Later passes: wave ballot +
+        // prefix, one atomic per block.
+        long long j;
+        if constexpr (FIRST) {
+            MCPT_LSTAMP(1)
+            if (!alive) continue;
+            j = first_pos;
+        } else {
         const unsigned long long bal = __ballot(alive);
         const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wave_tot[wv] = (unsigned int)__popcll(bal);
@@ -160,7 +171,8 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         __syncthreads();
         MCPT_LSTAMP(1)
         if (!alive) continue;
-        const long long j = off;
+        j = off;
+        }
 
         // ---- shade vertex `depth` at position j (pathTracing.cpp:147-241; the pieces are in vertex.hpp)
         const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
@@ -489,22 +501,36 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
 }
 
 // one PrimarySurface per hit pixel of the chunk (same arithmetic as the per-sample code it replaces: vertex_surface)
-__global__ void k_primary_surface(DScene S, WfArgs a, PrimarySurface* __restrict__ surf)
+__global__ void k_primary_surface(DScene S, WfArgs a, PrimarySurface* __restrict__ surf, unsigned int* __restrict__ alive_count)
 {
     const unsigned int n = a.counts_in->n_next;
-    for (unsigned int h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
+    const unsigned int n_round = (n + 63u) / 64u * 64u;              // whole waves take part in the ballot below
+    const int lane = threadIdx.x & 63;
+    for (unsigned int h = blockIdx.x * blockDim.x + threadIdx.x; h < n_round; h += gridDim.x * blockDim.x) {
+        bool shaded = false;
+        PrimarySurface r;
+        if (h < n) {
         const int slot = a.hit_slots[h];
         const PrimaryHit ph = a.hits[slot];
         const int pix = a.pixels ? a.pixels[slot] : slot;
-        PrimarySurface r;
         const V3 p = mk(ph.p[0], ph.p[1], ph.p[2]), dir = neg(ld3(a.dirs + (size_t)pix * 3));
         r.p[0] = p.x; r.p[1] = p.y; r.p[2] = p.z; r.dir[0] = dir.x; r.dir[1] = dir.y; r.dir[2] = dir.z;
         r.leaf = ph.leaf; r.material = S.tris[ph.leaf].material; r.pixel = pix; r.slot = slot;
         V3 pn = mk(0, 0, 0), kd = mk(0, 0, 0);
         const DMaterial* m = S.materials + r.material;
-        if (m->light < 0) vertex_surface(S, ph.leaf, p, m, pn, kd);
+        if (m->light < 0) { vertex_surface(S, ph.leaf, p, m, pn, kd); shaded = true; }
         r.pn[0] = pn.x; r.pn[1] = pn.y; r.pn[2] = pn.z; r.kd[0] = kd.x; r.kd[1] = kd.y; r.kd[2] = kd.z;
-        surf[h] = r;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        }
+        // the shaded pixels of the chunk, numbered (wave ballot + one atomic per wave; which number a pixel gets does not matter)
+        const unsigned long long bal = __ballot(shaded);
+        unsigned int base = 0;
+        if (bal && lane == __ffsll((long long)bal) - 1) base = atomicAdd(alive_count, (unsigned int)__popcll(bal));
+        if (bal) base = __shfl(base, __ffsll((long long)bal) - 1, 64);
+        if (h < n) {
+            r.alive_index = shaded ? (int32_t)(base + __popcll(bal & ((1ull << lane) - 1ull))) : -1;
+            surf[h] = r;
+        }
     }
 }
 
@@ -535,10 +561,10 @@ static unsigned grid_for(long long n, int block, unsigned cap_blocks)
     return (unsigned)(b > cap_blocks ? cap_blocks : b);
 }
 
-void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, int n_slots_upper, hipStream_t st)
+void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, unsigned int* alive_count, int n_slots_upper, hipStream_t st)
 {
     if (n_slots_upper <= 0) return;
-    hipLaunchKernelGGL(k_primary_surface, dim3(grid_for(n_slots_upper, 256, 4096)), dim3(256), 0, st, S, a, surf);
+    hipLaunchKernelGGL(k_primary_surface, dim3(grid_for(n_slots_upper, 256, 4096)), dim3(256), 0, st, S, a, surf, alive_count);
 }
 
 // A resident-size grid whose blocks stride over the paths: starting a block of this kernel is expensive (large kernarg,

@@ -46,6 +46,8 @@ struct alignas(16) PrimarySurface {
     double p[3], dir[3];        // hit point, direction back to the eye
     double pn[3], kd[3];        // interpolated normal and diffuse colour there (unset on an emitter)
     int32_t leaf, material, pixel, slot;
+    int32_t alive_index, pad[3];    // position of the pixel among the chunk's shaded (non-emitter) hit pixels, -1 on an emitter: the first
+                                    // logic pass puts sample k of the pixel at path position alive_index * spp + k, no compaction needed
 };
 
 struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
@@ -96,7 +98,7 @@ void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipSt
 int persistent_grid(const void* kernel, int cus);   // blocks of 256 threads of `kernel` resident on the current device
 long long persistent_chunk(long long total, int grid_blocks);
 
-void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, int n_slots_upper, hipStream_t st);
+void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, unsigned int* alive_count, int n_slots_upper, hipStream_t st);
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st);
 void launch_zero_rad(double* rad, long long n_doubles, hipStream_t st);
 

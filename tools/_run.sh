@@ -1,10 +1,4 @@
-mkdir -p gpurun_out/r2z
-for v in default lw4; do
-  if [ "$v" = default ]; then unset MCPT_LIB; else export MCPT_LIB=$PWD/montecarlopathtracing_amd/csrc/variants/libmcpt_$v.so; fi
-  for sc in "interior" "veach-mis --spp 100" "synthetic --spp 16"; do
-    timeout -k 10 300 python bench.py --scene $sc --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/r2z/b.json 2> gpurun_out/r2z/b.err || { tail -3 gpurun_out/r2z/b.err; continue; }
-    python -c "
-import json
-d=json.load(open('gpurun_out/r2z/b.json')); print('$v', '$sc', 'ms/frame %.2f'%(d['ms_per_step']))"
-  done
-done
+mkdir -p gpurun_out/r3a
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "pipelines or wavefront_iterations or image_matches or edge or partition or chunked or multi_device or pipelined or published" > gpurun_out/r3a/tests.log 2>&1 || { tail -30 gpurun_out/r3a/tests.log | cut -c1-250; exit 1; }
+tail -3 gpurun_out/r3a/tests.log
+bash tools/_bench_variants.sh gpurun_out/r3a default
