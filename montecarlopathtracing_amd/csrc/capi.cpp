@@ -122,6 +122,7 @@ struct mcpt_device {
         void* wf_ws = nullptr; size_t wf_ws_bytes = 0;
         int32_t* hit_slots = nullptr; int64_t hit_slots_cap = 0;
         PrimarySurface* surf = nullptr; int64_t surf_cap = 0;   // first-vertex record per hit pixel of the chunk
+        unsigned int* alive_base = nullptr; int64_t alive_base_cap = 0;   // shaded pixels before each group of 64 hit slots
         WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
         TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
         long long* slow_list = nullptr;
@@ -454,7 +455,7 @@ void mcpt_device_free(mcpt_device* d)
                     d->dirs, d->pixels};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& f : d->slot) {
-        void* q[] = {f.hits, f.rad, f.wf_ws, f.hit_slots, f.surf, f.wf_counts, f.queue, f.slow_list, f.ctr};
+        void* q[] = {f.hits, f.rad, f.wf_ws, f.hit_slots, f.surf, f.alive_base, f.wf_counts, f.queue, f.slow_list, f.ctr};
         for (void* p : q) if (p) (void)hipFree(p);
         if (f.done) (void)hipEventDestroy(f.done);
     }
@@ -937,10 +938,11 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
     int rc = grow(&f.hit_slots, &f.hit_slots_cap, chunk_slots);
     if (rc) return rc;
     if ((rc = grow(&f.surf, &f.surf_cap, chunk_slots))) return rc;
+    if ((rc = grow(&f.alive_base, &f.alive_base_cap, chunk_slots / 64 + 2))) return rc;
     WfArgs a{};
     WfState A, B;
     if (!wf_carve(f.wf_ws, f.wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
-    a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = f.hit_slots; a.surf = f.surf; a.hits = f.hits;
+    a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = f.hit_slots; a.surf = f.surf; a.alive_base = f.alive_base; a.hits = f.hits;
     a.dirs = d->dirs; a.rad = f.rad; a.counts = f.wf_counts; a.ctr = f.ctr; a.tris = d->tris;
     a.finish_below = fast ? unsigned(std::min<long long>(std::max<long long>(d->finish_threshold, 0), 1ll << 30)) : 0u;
     // Iterations are enqueued without waiting for their counts: every kernel reads its input count from the device slot the
@@ -967,7 +969,7 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
         a.first_slot = int(first);
         a.in = A; a.out = B;
         a.counts_in = &f.wf_counts[0];
-        launch_primary_surface(d->ds, a, f.surf, &f.wf_counts[0].pad[2], n_slots, st);      // what the samples of a pixel share at their first vertex
+        launch_primary_surface(d->ds, a, f.surf, f.alive_base, &f.wf_counts[0].pad[2], n_slots, st);      // what the samples of a pixel share at their first vertex
         HIP_TRY(hipGetLastError());
         for (int depth = 0; depth < MCPT_MAX_DEPTH && n_upper > 0; depth++) {
             a.depth = depth;

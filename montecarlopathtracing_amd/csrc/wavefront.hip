@@ -77,7 +77,9 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
 #else
 #define MCPT_LSTAMP(k)
 #endif
+#ifndef MCPT_FIRST_COMPACT
     if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) a.counts->n_next = a.counts_in->pad[2] * (unsigned int)a.spp;   // shaded pixels x samples
+#endif
     const long long n_round = (n_prev + 255) / 256 * 256;
     for (long long base = (long long)blockIdx.x * 256; base < n_round; base += (long long)gridDim.x * 256) {
 #ifdef MCPT_TRACE_DIAG
@@ -93,7 +95,18 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             if constexpr (FIRST) {
                 const PrimarySurface* ps = a.surf + i / a.spp;          // the same record for all samples of a pixel
                 const int k = (int)(i % a.spp);
-                first_pos = (long long)ps->alive_index * a.spp + k;
+                // Path positions in exact slot order trace measurably slower on a rank's share of a frame, so the pixels are shuffled
+                // within windows of 2^MCPT_SHUFFLE_LOG2 (an odd multiplier modulo a power of two is a bijection) -- close to the order
+                // the block-wise compaction used to leave.  One eighth of the frame, ms per frame by window: none (slot order) 18.8,
+                // 2^7 17.3, 2^10 16.5, 2^12 18.0, 2^14 18.7, 2^16 18.8; the whole frame is within 0.5 % for all of them.
+                unsigned int an = a.alive_base[(i / a.spp) >> 6] + (unsigned int)ps->alive_index;
+                const unsigned int n_alive = a.counts_in->pad[2];
+#ifndef MCPT_SHUFFLE_LOG2
+#define MCPT_SHUFFLE_LOG2 10
+#endif
+                constexpr unsigned int kWin = (1u << MCPT_SHUFFLE_LOG2) - 1u;
+                if ((an | kWin) < n_alive) an = (an & ~kWin) | ((an & kWin) * 40503u & kWin);      // (not in the last, partial window)
+                first_pos = (long long)an * a.spp + k;
                 id = (ps->slot - a.first_slot) * a.spp + k;
                 leaf = ps->leaf; mat_first = ps->material; pix_first = ps->pixel;
                 p = ld3(ps->p); dir = ld3(ps->dir); pn_first = ld3(ps->pn); kd_first = ld3(ps->kd);
@@ -150,11 +163,14 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         // pixels and sample k of pixel number n sits at n * spp + k (no ballot, no atomic, no barrier).  Later passes: wave ballot +
         // prefix, one atomic per block.
         long long j;
+#ifndef MCPT_FIRST_COMPACT
         if constexpr (FIRST) {
             MCPT_LSTAMP(1)
             if (!alive) continue;
             j = first_pos;
-        } else {
+        } else
+#endif
+        {
         const unsigned long long bal = __ballot(alive);
         const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wave_tot[wv] = (unsigned int)__popcll(bal);
@@ -522,16 +538,37 @@ __global__ void k_primary_surface(DScene S, WfArgs a, PrimarySurface* __restrict
         r.pn[0] = pn.x; r.pn[1] = pn.y; r.pn[2] = pn.z; r.kd[0] = kd.x; r.kd[1] = kd.y; r.kd[2] = kd.z;
         r.pad[0] = r.pad[1] = r.pad[2] = 0;
         }
-        // the shaded pixels of the chunk, numbered (wave ballot + one atomic per wave; which number a pixel gets does not matter)
+        // the shaded pixels of the chunk are numbered in slot order (paths in another order trace measurably slower on a rank's
+        // share of a frame): here the rank within the wave and the wave's count, k_alive_scan turns the counts into offsets
         const unsigned long long bal = __ballot(shaded);
-        unsigned int base = 0;
-        if (bal && lane == __ffsll((long long)bal) - 1) base = atomicAdd(alive_count, (unsigned int)__popcll(bal));
-        if (bal) base = __shfl(base, __ffsll((long long)bal) - 1, 64);
+        if (lane == 0) alive_count[h >> 6] = (unsigned int)__popcll(bal);
         if (h < n) {
-            r.alive_index = shaded ? (int32_t)(base + __popcll(bal & ((1ull << lane) - 1ull))) : -1;
+            r.alive_index = shaded ? (int32_t)__popcll(bal & ((1ull << lane) - 1ull)) : -1;
             surf[h] = r;
         }
     }
+}
+
+// exclusive prefix over the per-wave counts of k_primary_surface (at most a few thousand: one block), total -> *total_out
+__global__ void __launch_bounds__(1024) k_alive_scan(const WfCounts* __restrict__ counts_in, unsigned int* __restrict__ wave_count, unsigned int* __restrict__ total_out)
+{
+    __shared__ unsigned int part[1024];
+    const unsigned int n_waves = (counts_in->n_next + 63u) / 64u;
+    const unsigned int per = (n_waves + 1023u) / 1024u;
+    const unsigned int b = threadIdx.x * per, e = b + per < n_waves ? b + per : n_waves;
+    unsigned int sum = 0;
+    for (unsigned int i = b; i < e; i++) sum += wave_count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (unsigned int off = 1; off < 1024; off <<= 1) {
+        const unsigned int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned int run = part[threadIdx.x] - sum;              // exclusive prefix of this thread's range
+    for (unsigned int i = b; i < e; i++) { const unsigned int c = wave_count[i]; wave_count[i] = run; run += c; }
+    if (threadIdx.x == 1023) *total_out = part[1023];
 }
 
 
@@ -561,10 +598,12 @@ static unsigned grid_for(long long n, int block, unsigned cap_blocks)
     return (unsigned)(b > cap_blocks ? cap_blocks : b);
 }
 
-void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, unsigned int* alive_count, int n_slots_upper, hipStream_t st)
+void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, unsigned int* alive_count, unsigned int* alive_total, int n_slots_upper,
+                            hipStream_t st)
 {
     if (n_slots_upper <= 0) return;
     hipLaunchKernelGGL(k_primary_surface, dim3(grid_for(n_slots_upper, 256, 4096)), dim3(256), 0, st, S, a, surf, alive_count);
+    hipLaunchKernelGGL(k_alive_scan, dim3(1), dim3(1024), 0, st, a.counts_in, alive_count, alive_total);
 }
 
 // A resident-size grid whose blocks stride over the paths: starting a block of this kernel is expensive (large kernarg,

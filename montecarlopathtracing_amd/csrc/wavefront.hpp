@@ -46,8 +46,8 @@ struct alignas(16) PrimarySurface {
     double p[3], dir[3];        // hit point, direction back to the eye
     double pn[3], kd[3];        // interpolated normal and diffuse colour there (unset on an emitter)
     int32_t leaf, material, pixel, slot;
-    int32_t alive_index, pad[3];    // position of the pixel among the chunk's shaded (non-emitter) hit pixels, -1 on an emitter: the first
-                                    // logic pass puts sample k of the pixel at path position alive_index * spp + k, no compaction needed
+    int32_t alive_index, pad[3];    // rank of the pixel among the shaded (non-emitter) pixels of its group of 64 hit slots, -1 on an emitter:
+                                    // the first logic pass puts sample k at path position (alive_base[group] + alive_index) * spp + k -- no compaction
 };
 
 struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
@@ -72,6 +72,7 @@ struct WfArgs {
     const int32_t* pixels;      // slot -> pixel index (NULL: identity)
     const int32_t* hit_slots;   // first pass: compacted list of slots whose primary ray hit something
     const PrimarySurface* surf; // first pass: one record per entry of hit_slots
+    const unsigned int* alive_base;   // first pass: shaded pixels before each group of 64 entries of hit_slots (k_alive_scan)
     const PrimaryHit* hits;     // first pass: primary hit per slot
     const double* dirs;         // primary directions per pixel
     int first_slot;
@@ -98,7 +99,8 @@ void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipSt
 int persistent_grid(const void* kernel, int cus);   // blocks of 256 threads of `kernel` resident on the current device
 long long persistent_chunk(long long total, int grid_blocks);
 
-void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, unsigned int* alive_count, int n_slots_upper, hipStream_t st);
+void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, unsigned int* alive_count, unsigned int* alive_total, int n_slots_upper,
+                            hipStream_t st);
 void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st);
 void launch_zero_rad(double* rad, long long n_doubles, hipStream_t st);
 
