@@ -305,7 +305,7 @@ def main():
                          "record_bytes_rate_GBs": record_rate,
                          "record_bytes_note": "the same counts priced at this build's record sizes (64-B compressed 4-wide node, 104 B of an fp64 triangle): a cache-side rate, not a roofline",
                          "real_bound": "not HBM: the walk's 2.5 MB of nodes and triangles are served by L1/L2, fabric traffic is the streamed ray and hit records (traffic / peak ~ 7 %); "
-                                       "the kernel is bound by instruction issue of a 3-waves-per-SIMD state machine at ~57 % lane occupancy (DESIGN.md 6)",
+                                       "the kernel is bound by instruction issue (VALU ~90 % busy at 4 waves per SIMD) of a state machine at ~57 % lane occupancy (DESIGN.md 6)",
                          "issue_utilisation": issue,
                          "note": "rank-0 launches of k_wf_trace, timed with HIP events on the launching stream"},
         }

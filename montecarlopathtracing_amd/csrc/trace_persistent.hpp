@@ -58,8 +58,11 @@ namespace mcpt {
 #ifndef MCPT_INBAND_INPLACE
 #define MCPT_INBAND_INPLACE 0       /* how two candidates the products cannot rank are told apart: 1 = by the reference's own t_k and leaf index on
                                        the spot; 2 = the contender is remembered and the two are ranked where the ray is finished (fewer
-                                       registers in the triangle phase; a second contender sends the ray to the exact walk); 0 = the ray
-                                       goes to the exact walk */
+                                       registers in the triangle phase; a second contender sends the ray to the exact walk); 3 = by t_k and leaf
+                                       index on the spot without the newcomer's own-box test (the leader's is checked at the end anyway);
+                                       0 = the ray goes to the exact walk.  At 4 waves per SIMD (128 VGPRs) every register in the triangle
+                                       phase counts: mode 1 spills 20 registers, mode 2 27, mode 3 two -- and is still 11 % slower per launch
+                                       than mode 0, whose deferred rays (0.05 % on cornell-box) cost 0.13 ms per launch */
 #endif
 #ifndef MCPT_LAZY_VERIFY
 #define MCPT_LAZY_VERIFY 1          /* 1: a triangle whose test passes only has the RANK of its distance looked at (two multiplies);
@@ -364,6 +367,17 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                             // at all.  The leader's own box is looked at when the ray is finished, like any leader's.
 #if !MCPT_INBAND_INPLACE
                             ambiguous = true;
+#elif MCPT_INBAND_INPLACE == 3
+                            // the reference's own order of the two, (t_k, k): whether either is a candidate at all (its own box) is not
+                            // looked at here -- a non-candidate that takes or keeps the lead here can only be displaced by something
+                            // closer still, and if it is still leading when the ray is finished the own-box test there sends the ray
+                            // to the exact walk
+                            {
+                                const double t_new = (p.x - r.o.x) / r.d.x, t_old = (best.p.x - r.o.x) / r.d.x;
+                                if (t_new < t_old || (t_new == t_old && tr->leaf < tris[best.leaf].leaf)) {
+                                    best.leaf = tri_i - 1; best.t = ta; best.p = p;
+                                }
+                            }
 #elif MCPT_INBAND_INPLACE == 2
                             if (alt < 0) alt = tri_i - 1; else ambiguous = true;
 #else
