@@ -56,13 +56,14 @@ namespace mcpt {
                                        dropped instead of visited */
 #endif
 #ifndef MCPT_INBAND_INPLACE
-#define MCPT_INBAND_INPLACE 0       /* how two candidates the products cannot rank are told apart: 1 = by the reference's own t_k and leaf index on
+#define MCPT_INBAND_INPLACE 3       /* how two candidates the products cannot rank are told apart: 1 = by the reference's own t_k and leaf index on
                                        the spot; 2 = the contender is remembered and the two are ranked where the ray is finished (fewer
                                        registers in the triangle phase; a second contender sends the ray to the exact walk); 3 = by t_k and leaf
                                        index on the spot without the newcomer's own-box test (the leader's is checked at the end anyway);
                                        0 = the ray goes to the exact walk.  At 4 waves per SIMD (128 VGPRs) every register in the triangle
-                                       phase counts: mode 1 spills 20 registers, mode 2 27, mode 3 two -- and is still 11 % slower per launch
-                                       than mode 0, whose deferred rays (0.05 % on cornell-box) cost 0.13 ms per launch */
+                                       phase counts: mode 1 spills 20 registers, mode 2 27; mode 3 with two spilled registers was 11 % slower
+                                       per launch than mode 0 (whose deferred rays, 0.05 % on cornell-box, cost 0.13 ms per launch), with one
+                                       (after the per-lane rank mask went: v_mbcnt) it is 2.5 % faster: 7.37 vs 7.56 ms */
 #endif
 #ifndef MCPT_LAZY_VERIFY
 #define MCPT_LAZY_VERIFY 1          /* 1: a triangle whose test passes only has the RANK of its distance looked at (two multiplies);
@@ -101,7 +102,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     const long long small = chunk < MCPT_TAIL_CHUNK ? chunk : MCPT_TAIL_CHUNK;
     const long long big_tickets = (total - total / 8) / chunk;
     const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int* __restrict__ rayflag = reinterpret_cast<int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
     int* __restrict__ owner_of = rayflag + 64;      // MCPT_TRI_SHARE: pair slot -> owning lane | (triangle offset << 8)
     (void)owner_of;
@@ -240,7 +240,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                 const int want = __popcll(idle);
                 const int avail = lds_count - lds_taken;
                 const int give = want < avail ? want : avail;
-                const int rank = __popcll(idle & lt_mask);
+                // set bits of `idle` below this lane (v_mbcnt: no per-lane mask register to keep)
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
                 if (state == ST_IDLE && rank < give) {
                     const int e = lds_taken + rank;
                     if (rayflag[e]) {
