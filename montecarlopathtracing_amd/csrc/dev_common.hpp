@@ -41,13 +41,18 @@ __device__ __forceinline__ double dmax3(double p1, double p2, double p3)
 }
 
 // ------------------------------------------------------------------------------------------------ RNG seam (D1)
-// Philox4x32-10, counter (pixel, sample, depth<<16 | slot>>1, 'MCPT'), key = seed.  Even slots use words 0,1
-// of the block, odd slots words 2,3; 53 bits -> [0,1).
+// Philox4x32-10, counter (pixel, sample, depth<<16 | block, 'MCPT'), key = seed.  A path vertex numbers its uniforms by slot
+// (light l: 4l..4l+3, then RR, FRESNEL, LOBE, PHI, THETA); slot s is word s & 3 of block s >> 2 and a word w becomes
+// (w + 0.5) * 2^-32, a uniform on the open interval (0,1) with 32 random bits -- nl + 2 blocks per vertex (round 1 spent a
+// block on two 53-bit uniforms, 2 nl + 3 blocks per vertex; the generator was a fifth of the logic kernels' instructions).
 struct Philox { uint32_t v[4]; };
 __device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
+#ifndef MCPT_PHILOX_ROUNDS
+#define MCPT_PHILOX_ROUNDS 10          /* anything else is a timing experiment, not a generator */
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < MCPT_PHILOX_ROUNDS; r++) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
@@ -57,23 +62,18 @@ __device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32
     Philox p; p.v[0] = c0; p.v[1] = c1; p.v[2] = c2; p.v[3] = c3;
     return p;
 }
-__device__ __forceinline__ double bits_to_unit(uint32_t h, uint32_t l)
-{
-    const unsigned long long bits = ((static_cast<unsigned long long>(h) << 32) | l) >> 11;
-    return static_cast<double>(bits) * (1.0 / 9007199254740992.0);
-}
+__device__ __forceinline__ double word_to_unit(uint32_t w) { return __builtin_fma((double)w, 0x1p-32, 0x1p-33); }   // exact
 struct RngKey { uint32_t k0, k1, pixel, sample; };
-__device__ __forceinline__ double uniform(const RngKey& k, uint32_t depth, uint32_t slot)
-{
-    const Philox p = philox4x32_10(k.pixel, k.sample, (depth << 16) | (slot >> 1), 0x4D435054u, k.k0, k.k1);
-    return (slot & 1u) ? bits_to_unit(p.v[2], p.v[3]) : bits_to_unit(p.v[0], p.v[1]);
-}
-// two consecutive slots (2b, 2b+1) from one block
-__device__ __forceinline__ void uniform2(const RngKey& k, uint32_t depth, uint32_t block, double& u0, double& u1)
+// slots 4b .. 4b+3
+__device__ __forceinline__ void uniform4(const RngKey& k, uint32_t depth, uint32_t block, double& u0, double& u1, double& u2, double& u3)
 {
     const Philox p = philox4x32_10(k.pixel, k.sample, (depth << 16) | block, 0x4D435054u, k.k0, k.k1);
-    u0 = bits_to_unit(p.v[0], p.v[1]);
-    u1 = bits_to_unit(p.v[2], p.v[3]);
+    u0 = word_to_unit(p.v[0]); u1 = word_to_unit(p.v[1]); u2 = word_to_unit(p.v[2]); u3 = word_to_unit(p.v[3]);
+}
+// slot 4b
+__device__ __forceinline__ double uniform1(const RngKey& k, uint32_t depth, uint32_t block)
+{
+    return word_to_unit(philox4x32_10(k.pixel, k.sample, (depth << 16) | block, 0x4D435054u, k.k0, k.k1).v[0]);
 }
 
 // ------------------------------------------------------------------------------------------------ hit tests

@@ -56,11 +56,10 @@ __device__ void shade_path_from(const DScene& S, const RngKey& key, uint32_t dep
             const DLight* lt = S.lights + i;
             V3 xl = mk(0, 0, 0), vn = mk(0, 0, 0);
             double u0, u1, u2, u3;
-            uniform2(key, depth, 2u * i, u0, u1);
+            uniform4(key, depth, i, u0, u1, u2, u3);
             const double rnd = u0 * S.area0;                                    // frozen static u1 range (Q1)
             const int j = pick_light_triangle(S.light_cdf + lt->first, lt->ntri, lt->cdf_sorted != 0, rnd);
             if (j >= 0) {
-                uniform2(key, depth, 2u * i + 1u, u2, u3);
                 const DLightTri* q = S.light_tris + lt->first + j;
                 sample_mat = lt->material;
                 const double rnd1 = u1, rnd2 = u2, rnd3 = u3;
@@ -78,9 +77,9 @@ __device__ void shade_path_from(const DScene& S, const RngKey& key, uint32_t dep
             const int inter_mat = got ? S.tris[inter.leaf].material : -1;
             if (inter_mat != sample_mat) visibility = 0;                        // :213
             if (dot(direction, pn) > 0) {
-                                const double cos_theta = fabs(dot(direction, vn) * frcp(norm(direction)) * frcp(norm(vn)));
-                const double cos_theta_hat = fabs(dot(direction, pn) * frcp(norm(direction)) * frcp(norm(pn)));
-                const double dd = norm(xl - hit.p);
+                const double cos_theta = fabs(dot(direction, vn) * frcp(norm_s(vn)));
+                const double cos_theta_hat = fabs(dot(direction, pn) * frcp(norm_s(pn)));
+                const double dd = norm_s(xl - hit.p);
                 const double dist = (1.0 < dd) ? dd : 1.0;                      // std::max(1.0, distance)
                 const V3 intensity = (((ld3(lt->radiance) * cos_theta) * cos_theta_hat) * (frcp(sqr(dist)) * lt->total_area)) * visibility;
                 const double kd_dots = dot(direction, pn);
@@ -95,8 +94,8 @@ __device__ void shade_path_from(const DScene& S, const RngKey& key, uint32_t dep
 
         // indirect illumination, :234-263
         if (depth + 1 >= MCPT_MAX_DEPTH_DEV) break;                             // D6
-        double u_rr, u_fresnel;
-        uniform2(key, depth, 2u * nl, u_rr, u_fresnel);                         // slots 4nl (RR), 4nl+1 (FRESNEL)
+        double u_rr, u_fresnel, u_lobe, u_phi;
+        uniform4(key, depth, nl, u_rr, u_fresnel, u_lobe, u_phi);               // slots 4nl (RR), 4nl+1 (FRESNEL), 4nl+2 (LOBE), 4nl+3 (PHI)
         if (!(u_rr < MCPT_P_RR)) break;                                         // russian_Roulette :3-11
         // nextRay, :66-134
         Ray nr; int type = -1;
@@ -119,12 +118,10 @@ __device__ void shade_path_from(const DScene& S, const RngKey& key, uint32_t dep
             }
         }
         if (type < 0) {
-            double u_lobe, u_phi, u_theta, unused;
-            uniform2(key, depth, 2u * nl + 1u, u_lobe, u_phi);                  // slots 4nl+2 (LOBE), 4nl+3 (PHI)
-            uniform2(key, depth, 2u * nl + 2u, u_theta, unused);                // slot 4nl+4 (THETA)
-            const double kd_norm = norm(kd), ks_norm = norm(ks);
+            const double u_theta = uniform1(key, depth, nl + 1u);               // slot 4nl+4 (THETA)
+            const double ks_norm = norm_s(ks);
             V3 direction;
-            if (ks_norm != 0 && kd_norm / ks_norm < u_lobe) {
+            if (ks_norm != 0 && norm_s(kd) * frcp(ks_norm) < u_lobe) {
                 const V3 incoming = neg(dir);
                 const V3 reflect = incoming - (pn * dot(incoming, pn)) * 2;
                 direction = brdf_sample(u_phi, u_theta, reflect, RT_SPECULAR, m->Ns);

@@ -36,11 +36,10 @@ __device__ __forceinline__ int light_sample(const DScene& S, const RngKey& key, 
     const DLight* lt = S.lights + l;
     V3 xl = mk(0, 0, 0), vn = mk(0, 0, 0);
     double u0, u1, u2, u3;
-    uniform2(key, depth, 2u * l, u0, u1);
+    uniform4(key, depth, (uint32_t)l, u0, u1, u2, u3);
     const double rnd = u0 * S.area0;                                            // frozen static u1 range (Q1)
     const int jt = pick_light_triangle(S.light_cdf + lt->first, lt->ntri, lt->cdf_sorted != 0, rnd);
     if (jt >= 0) {
-        uniform2(key, depth, 2u * l + 1u, u2, u3);
         const DLightTri* q = S.light_tris + lt->first + jt;
         sample_mat = lt->material;
         const double isum = frcp(u1 + u2 + u3);
@@ -51,9 +50,10 @@ __device__ __forceinline__ int light_sample(const DScene& S, const RngKey& key, 
     direction = normalized_s(xl - p);
     const double kd_dots = dot(direction, pn);
     if (!(kd_dots > 0)) return -2;
-    const double cos_theta = fabs(dot(direction, vn) * frcp(norm(direction)) * frcp(norm(vn)));
-    const double cos_theta_hat = fabs(dot(direction, pn) * frcp(norm(direction)) * frcp(norm(pn)));
-    const double dd = norm(xl - p);
+    // (the reference also divides by |direction|, a unit vector: 1 to within the two ulps this arithmetic is held to)
+    const double cos_theta = fabs(dot(direction, vn) * frcp(norm_s(vn)));
+    const double cos_theta_hat = fabs(kd_dots * frcp(norm_s(pn)));
+    const double dd = norm_s(xl - p);
     const double dist = (1.0 < dd) ? dd : 1.0;                                  // std::max(1.0, distance)
     const V3 intensity = ((ld3(lt->radiance) * cos_theta) * cos_theta_hat) * (frcp(sqr(dist)) * lt->total_area);
     c = mk(kd.x * intensity.x * kd_dots * MCPT_INV_PI, kd.y * intensity.y * kd_dots * MCPT_INV_PI, kd.z * intensity.z * kd_dots * MCPT_INV_PI);
@@ -68,8 +68,8 @@ __device__ __forceinline__ int bounce_sample(const RngKey& key, uint32_t depth, 
                                              V3& nd, V3& wgt)
 {
     if (depth + 1 >= MCPT_MAX_DEPTH_DEV) return -1;                            // D6
-    double u_rr, u_fresnel;
-    uniform2(key, depth, 2u * nl, u_rr, u_fresnel);
+    double u_rr, u_fresnel, u_lobe, u_phi;
+    uniform4(key, depth, (uint32_t)nl, u_rr, u_fresnel, u_lobe, u_phi);
     if (!(u_rr < MCPT_P_RR)) return -1;
     int btype = -1, at_vertex = 0;
     const V3 ks = ld3(m->ks);
@@ -92,11 +92,9 @@ __device__ __forceinline__ int bounce_sample(const RngKey& key, uint32_t depth, 
         }
     }
     if (btype < 0) {
-        double u_lobe, u_phi, u_theta, unused;
-        uniform2(key, depth, 2u * nl + 1u, u_lobe, u_phi);
-        uniform2(key, depth, 2u * nl + 2u, u_theta, unused);
-        const double kd_norm = norm(kd), ks_norm = norm(ks);
-        if (ks_norm != 0 && kd_norm / ks_norm < u_lobe) {
+        const double u_theta = uniform1(key, depth, (uint32_t)nl + 1u);
+        const double ks_norm = norm_s(ks);
+        if (ks_norm != 0 && norm_s(kd) * frcp(ks_norm) < u_lobe) {
             const V3 incoming = neg(dir);
             const V3 reflect = incoming - (pn * dot(incoming, pn)) * 2;
             nd = brdf_sample(u_phi, u_theta, reflect, RT_SPECULAR, m->Ns);

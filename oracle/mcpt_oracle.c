@@ -119,18 +119,15 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* One uniform in [0,1) with 53 random bits.  Counter = (pixel, sample, depth<<16 | slot>>1, 'MCPT'),
- * key = seed; even slots take words 0,1 and odd slots words 2,3 of the Philox block. */
+/* One uniform on the open interval (0,1) with 32 random bits: word slot & 3 of the Philox block with counter
+ * (pixel, sample, depth<<16 | slot>>2, 'MCPT') and key = seed, as (word + 0.5) * 2^-32 (exact in a double). */
 double orc_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t depth, uint32_t slot)
 {
-    uint32_t ctr[4] = { pixel, sample, (depth << 16) | (slot >> 1), 0x4D435054u };
+    uint32_t ctr[4] = { pixel, sample, (depth << 16) | (slot >> 2), 0x4D435054u };
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     uint32_t o[4];
     orc_philox4x32_10(ctr, key, o);
-    uint32_t h = (slot & 1u) ? o[2] : o[0];
-    uint32_t l = (slot & 1u) ? o[3] : o[1];
-    uint64_t bits = (((uint64_t)h << 32) | (uint64_t)l) >> 11;
-    return (double)bits * (1.0 / 9007199254740992.0);
+    return ((double)o[slot & 3u] + 0.5) * (1.0 / 4294967296.0);
 }
 
 /* ------------------------------------------------------------------ Morton key

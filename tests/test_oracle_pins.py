@@ -28,15 +28,17 @@ def test_philox_known_answers(oracle):
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def test_uniform_is_53_bit_unit_interval(oracle):
+def test_uniform_is_a_32_bit_word_on_the_open_unit_interval(oracle):
     u = np.array([oracle.uniform(7, p, k, d, s) for p in range(4) for k in range(4) for d in range(3) for s in range(9)])
-    assert (u >= 0).all() and (u < 1).all()
+    assert (u > 0).all() and (u < 1).all()
     assert len(np.unique(u)) == len(u)
-    assert np.all(u * 2.0 ** 53 == np.floor(u * 2.0 ** 53))
-    # slots 2b and 2b+1 come from one Philox block: words (0,1) and (2,3)
-    o = oracle.philox([3, 5, (2 << 16) | 4, 0x4D435054], [9, 0])
-    assert oracle.uniform(9, 3, 5, 2, 8) == ((o[0] << 32 | o[1]) >> 11) * 2.0 ** -53
-    assert oracle.uniform(9, 3, 5, 2, 9) == ((o[2] << 32 | o[3]) >> 11) * 2.0 ** -53
+    assert np.all(u * 2.0 ** 33 == np.floor(u * 2.0 ** 33)) and np.all((u * 2.0 ** 33) % 2 == 1)
+    # slots 4b .. 4b+3 are the four words of one Philox block
+    o = oracle.philox([3, 5, (2 << 16) | 2, 0x4D435054], [9, 0])
+    for w in range(4):
+        assert oracle.uniform(9, 3, 5, 2, 8 + w) == (o[w] + 0.5) * 2.0 ** -32
+    o = oracle.philox([3, 5, (2 << 16) | 3, 0x4D435054], [0x12345678, 0x9])
+    assert oracle.uniform(0x912345678, 3, 5, 2, 12) == (o[0] + 0.5) * 2.0 ** -32
 
 
 def test_morton_against_committed_reference_vectors(oracle):
