@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
@@ -45,6 +46,17 @@ struct Box {
     }
 };
 
+// fn(begin, end, part) for `parts` contiguous pieces of [b, e), one thread each (the caller's included); returns when all are done
+template <class F>
+static void fork_join(int b, int e, int parts, F fn)
+{
+    const long long n = e - b;
+    std::vector<std::thread> pool;
+    for (int p = 1; p < parts; p++) pool.emplace_back([=]() { fn(int(b + n * p / parts), int(b + n * (p + 1) / parts), p); });
+    fn(b, int(b + n / parts), 0);
+    for (std::thread& th : pool) th.join();
+}
+
 // A subtree the top-level pass leaves to a worker thread: primitives idx[b, e) at `depth`, to be hung under parent.child[slot].
 struct Subtree { int b, e, depth; int32_t parent; int slot; };
 
@@ -57,6 +69,13 @@ struct Builder {
     int cut = 0;
     int max_leaf = kFastDefaultLeaf;         // most primitives a leaf may hold
     int depth_limit = kFastMaxDepth;         // binary depth the tree must stay below (the walk's stack)
+    // Top-level pass of a large scene: the loops over a node's primitives (bounds, bins, partition) run on `threads` threads while the
+    // node has at least kParallelMin of them -- minima, maxima and counts are merged exactly, so the splits are those of the serial
+    // build; only the order inside a range differs, which nothing depends on (leaves sort their triangles, the median split orders by
+    // (value, index)).  10 M triangles on 16 threads: 1.0 s of single-threaded top levels -> see DESIGN.md 6.
+    int threads = 1;
+    std::vector<int32_t>* scratch = nullptr; // as long as idx: the partition's second buffer
+    static constexpr int kParallelMin = 1 << 16;
 
     Builder(const std::vector<Box>& p, const std::vector<Vec3>& c, std::vector<int32_t>& i, FastBvh& o) : prim(p), cen(c), idx(i), out(o) {}
 
@@ -66,6 +85,18 @@ struct Builder {
     {
         Box r; r.reset();
         for (int i = b; i < e; i++) r.grow(prim[idx[i]]);
+        return r;
+    }
+
+    bool wide(int n) const { return threads > 1 && scratch && n >= kParallelMin; }
+
+    Box bounds_wide(int b, int e) const
+    {
+        if (!wide(e - b)) return bounds(b, e);
+        std::vector<Box> part(size_t(threads), Box{});
+        fork_join(b, e, threads, [&](int cb_, int ce_, int p) { part[size_t(p)] = bounds(cb_, ce_); });
+        Box r; r.reset();
+        for (const Box& q : part) r.grow(q);
         return r;
     }
 
@@ -91,57 +122,122 @@ struct Builder {
         out.max_depth = std::max(out.max_depth, depth);
         if (n <= 1) return make_leaf(b, e);
         const bool force_balanced = depth + ceil_log2(n) >= depth_limit - 1;
+        const bool par = wide(n);
+        auto centre_bounds = [&](int cb_, int ce_) {
+            Box r; r.reset();
+            for (int i = cb_; i < ce_; i++) {
+                const Vec3& c = cen[idx[i]];
+                r.lo[0] = std::min(r.lo[0], c.x); r.hi[0] = std::max(r.hi[0], c.x);
+                r.lo[1] = std::min(r.lo[1], c.y); r.hi[1] = std::max(r.hi[1], c.y);
+                r.lo[2] = std::min(r.lo[2], c.z); r.hi[2] = std::max(r.hi[2], c.z);
+            }
+            return r;
+        };
         Box cb; cb.reset();
-        for (int i = b; i < e; i++) {
-            const Vec3& c = cen[idx[i]];
-            cb.lo[0] = std::min(cb.lo[0], c.x); cb.hi[0] = std::max(cb.hi[0], c.x);
-            cb.lo[1] = std::min(cb.lo[1], c.y); cb.hi[1] = std::max(cb.hi[1], c.y);
-            cb.lo[2] = std::min(cb.lo[2], c.z); cb.hi[2] = std::max(cb.hi[2], c.z);
-        }
+        if (par) {
+            std::vector<Box> part(size_t(threads), Box{});
+            fork_join(b, e, threads, [&](int cb_, int ce_, int p) { part[size_t(p)] = centre_bounds(cb_, ce_); });
+            for (const Box& q : part) cb.grow(q);
+        } else cb = centre_bounds(b, e);
         int mid = -1;
+        bool have_kid_boxes = false;
+        Box lb, rb;
         if (!force_balanced) {
-            const Box nb = bounds(b, e);
+            // bins of the three axes in one pass over the primitives (an axis without extent has none)
+            struct Bins { Box bb[3][kBins]; int cnt[3][kBins]; };
+            double scale[3]; bool use[3];
+            for (int a = 0; a < 3; a++) { const double ext = cb.hi[a] - cb.lo[a]; use[a] = ext > 0; scale[a] = use[a] ? kBins * (1.0 - 1e-12) / ext : 0.0; }
+            auto clear_bins = [](Bins& q) { for (int a = 0; a < 3; a++) for (int k = 0; k < kBins; k++) { q.bb[a][k].reset(); q.cnt[a][k] = 0; } };
+            auto fill_bins = [&](int cb_, int ce_, Bins& q) {
+                for (int i = cb_; i < ce_; i++) {
+                    const int32_t pi = idx[i];
+                    const Vec3& c = cen[pi];
+                    const double v[3] = {c.x, c.y, c.z};
+                    for (int a = 0; a < 3; a++) {
+                        if (!use[a]) continue;
+                        int k = int((v[a] - cb.lo[a]) * scale[a]);
+                        k = std::min(std::max(k, 0), kBins - 1);
+                        q.bb[a][k].grow(prim[pi]); q.cnt[a][k]++;
+                    }
+                }
+            };
+            Bins B;                              // (on the stack: this runs once per node, ten million times)
+            clear_bins(B);
+            if (par) {
+                std::vector<Bins> part;
+                part.resize(size_t(threads));
+                fork_join(b, e, threads, [&](int cb_, int ce_, int p) { clear_bins(part[size_t(p)]); fill_bins(cb_, ce_, part[size_t(p)]); });
+                for (const Bins& q : part)
+                    for (int a = 0; a < 3; a++) for (int k = 0; k < kBins; k++) { B.bb[a][k].grow(q.bb[a][k]); B.cnt[a][k] += q.cnt[a][k]; }
+            } else fill_bins(b, e, B);
+            // the node's own box: the union of any used axis' bins (every primitive is in exactly one bin per axis), else by a pass
+            Box nb; nb.reset();
+            { int a0 = use[0] ? 0 : (use[1] ? 1 : (use[2] ? 2 : -1));
+              if (a0 >= 0) { for (int k = 0; k < kBins; k++) if (B.cnt[a0][k]) nb.grow(B.bb[a0][k]); } else nb = bounds_wide(b, e); }
             const double parent_area = nb.half_area();
             double best = std::numeric_limits<double>::infinity();
             int best_axis = -1, best_bin = -1;
             for (int a = 0; a < 3; a++) {
-                const double ext = cb.hi[a] - cb.lo[a];
-                if (!(ext > 0)) continue;
-                Box bb[kBins]; int cnt[kBins];
-                for (int k = 0; k < kBins; k++) { bb[k].reset(); cnt[k] = 0; }
-                const double scale = kBins * (1.0 - 1e-12) / ext;
-                auto ca = [&](int i) { const Vec3& c = cen[idx[i]]; return a == 0 ? c.x : (a == 1 ? c.y : c.z); };
-                for (int i = b; i < e; i++) {
-                    int k = int((ca(i) - cb.lo[a]) * scale);
-                    k = std::min(std::max(k, 0), kBins - 1);
-                    bb[k].grow(prim[idx[i]]); cnt[k]++;
-                }
+                if (!use[a]) continue;
+                const Box* bb = B.bb[a]; const int* cnt = B.cnt[a];
+                // Only the occupied bins take part: a split behind an empty bin has the sides, hence the cost, of the split before
+                // it and is never strictly better.  Most nodes of a tree are tiny (ten million of them hold one or two triangles).
+                int nz[kBins], m = 0;
+                for (int k = 0; k < kBins; k++) if (cnt[k]) nz[m++] = k;
+                if (m < 2) continue;
                 double right_area[kBins]; int right_cnt[kBins];
                 Box acc; acc.reset(); int c = 0;
-                for (int k = kBins - 1; k > 0; k--) { acc.grow(bb[k]); c += cnt[k]; right_area[k] = acc.half_area(); right_cnt[k] = c; }
+                for (int j = m - 1; j > 0; j--) { acc.grow(bb[nz[j]]); c += cnt[nz[j]]; right_area[j] = acc.half_area(); right_cnt[j] = c; }
                 acc.reset(); c = 0;
-                for (int k = 0; k + 1 < kBins; k++) {
-                    acc.grow(bb[k]); c += cnt[k];
-                    if (c == 0 || right_cnt[k + 1] == 0) continue;
-                    const double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
-                    if (cost < best) { best = cost; best_axis = a; best_bin = k; }
+                for (int j = 0; j + 1 < m; j++) {
+                    acc.grow(bb[nz[j]]); c += cnt[nz[j]];
+                    const double cost = acc.half_area() * c + right_area[j + 1] * right_cnt[j + 1];
+                    if (cost < best) { best = cost; best_axis = a; best_bin = nz[j]; }
                 }
             }
             if (best_axis >= 0) {
                 const double split_cost = kCostNode + kCostTri * best / std::max(parent_area, 1e-300);
                 if (n <= max_leaf && kCostTri * n <= split_cost) return make_leaf(b, e);
                 const int a = best_axis;
-                const double ext = cb.hi[a] - cb.lo[a];
-                const double scale = kBins * (1.0 - 1e-12) / ext;
-                auto it = std::partition(idx.begin() + b, idx.begin() + e, [&](int32_t p) {
+                auto goes_left = [&](int32_t p) {
                     const Vec3& c = cen[p];
                     const double v = a == 0 ? c.x : (a == 1 ? c.y : c.z);
-                    int k = int((v - cb.lo[a]) * scale);
+                    int k = int((v - cb.lo[a]) * scale[a]);
                     k = std::min(std::max(k, 0), kBins - 1);
                     return k <= best_bin;
-                });
-                mid = int(it - idx.begin());
+                };
+                if (par) {
+                    // left and right parts of every thread's piece, in piece order, through the second buffer
+                    std::vector<int> nleft(size_t(threads), 0), first(size_t(threads), 0), last(size_t(threads), 0);
+                    fork_join(b, e, threads, [&](int cb_, int ce_, int p) {
+                        int c = 0;
+                        for (int i = cb_; i < ce_; i++) c += goes_left(idx[i]) ? 1 : 0;
+                        nleft[size_t(p)] = c; first[size_t(p)] = cb_; last[size_t(p)] = ce_;
+                    });
+                    int total_left = 0;
+                    for (int c : nleft) total_left += c;
+                    std::vector<int> lo_at(size_t(threads), 0), hi_at(size_t(threads), 0);
+                    { int l = b, r = b + total_left;
+                      for (int p = 0; p < threads; p++) { lo_at[size_t(p)] = l; hi_at[size_t(p)] = r; l += nleft[size_t(p)]; r += (last[size_t(p)] - first[size_t(p)]) - nleft[size_t(p)]; } }
+                    std::vector<int32_t>& tmp = *scratch;
+                    fork_join(b, e, threads, [&](int cb_, int ce_, int p) {
+                        int l = lo_at[size_t(p)], r = hi_at[size_t(p)];
+                        for (int i = cb_; i < ce_; i++) { const int32_t v = idx[i]; if (goes_left(v)) tmp[size_t(l++)] = v; else tmp[size_t(r++)] = v; }
+                    });
+                    fork_join(b, e, threads, [&](int cb_, int ce_, int) { std::copy(tmp.begin() + cb_, tmp.begin() + ce_, idx.begin() + cb_); });
+                    mid = b + total_left;
+                } else {
+                    auto it = std::partition(idx.begin() + b, idx.begin() + e, goes_left);
+                    mid = int(it - idx.begin());
+                }
                 if (mid == b || mid == e) mid = -1;
+                else {
+                    // the children's boxes are the unions of the bins on either side of the split (the same minima and maxima a pass
+                    // over their primitives finds)
+                    lb.reset(); rb.reset();
+                    for (int k = 0; k < kBins; k++) if (B.cnt[a][k]) (k <= best_bin ? lb : rb).grow(B.bb[a][k]);
+                    have_kid_boxes = true;
+                }
             } else if (n <= max_leaf) {
                 return make_leaf(b, e);     // all centroids coincide
             }
@@ -158,8 +254,8 @@ struct Builder {
             });
         }
         const int32_t self = int32_t(out.nodes.size());
-        out.nodes.emplace_back();
-        const Box lb = bounds(b, mid), rb = bounds(mid, e);
+        out.nodes.emplace_back(FastNode{});
+        if (!have_kid_boxes) { lb = bounds_wide(b, mid); rb = bounds_wide(mid, e); }
         const int32_t l = child(b, mid, depth + 1, self, 0);
         const int32_t r = child(mid, e, depth + 1, self, 1);
         FastNode& nd = out.nodes[self];
@@ -187,6 +283,7 @@ struct Collapser {
 
     int compute_height(int n)
     {
+        if (height[n] > 0) return height[n];        // done already (a subtree a worker has been through; every inner node has height >= 1)
         int h = 0, cnt = 1;
         for (int c = 0; c < 2; c++) {
             const int32_t r = in.nodes[n].child[c];
@@ -295,16 +392,25 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
     double amax = 0;
     auto mx3 = [](double a, double b, double c) { if (a >= b && a >= c) return a; if (b >= a && b >= c) return b; return c; };   // dmax
     auto mn3 = [](double a, double b, double c) { if (a <= b && a <= c) return a; if (b <= a && b <= c) return b; return c; };   // dmin
-    for (int k = 0; k < t; k++) {
-        const FaceRec& f = faces[order[k]];            // the reference's own leaf box of leaf k (BVH.cpp:87-97)
-        prim[k].lo[0] = mn3(f.v[0].x, f.v[1].x, f.v[2].x); prim[k].hi[0] = mx3(f.v[0].x, f.v[1].x, f.v[2].x);
-        prim[k].lo[1] = mn3(f.v[0].y, f.v[1].y, f.v[2].y); prim[k].hi[1] = mx3(f.v[0].y, f.v[1].y, f.v[2].y);
-        prim[k].lo[2] = mn3(f.v[0].z, f.v[1].z, f.v[2].z); prim[k].hi[2] = mx3(f.v[0].z, f.v[1].z, f.v[2].z);
-        for (int a = 0; a < 3; a++) {
-            if (std::isfinite(prim[k].lo[a])) amax = std::max(amax, std::fabs(prim[k].lo[a]));
-            if (std::isfinite(prim[k].hi[a])) amax = std::max(amax, std::fabs(prim[k].hi[a]));
+    const auto t_start = std::chrono::steady_clock::now();
+    std::mutex amax_mu;
+    parallel_pieces(t, [&](long long kb, long long ke) {
+        double am = 0;
+        for (long long k = kb; k < ke; k++) {
+            const FaceRec& f = faces[size_t(order[k])];    // the reference's own leaf box of leaf k (BVH.cpp:87-97)
+            Box& q = prim[size_t(k)];
+            q.lo[0] = mn3(f.v[0].x, f.v[1].x, f.v[2].x); q.hi[0] = mx3(f.v[0].x, f.v[1].x, f.v[2].x);
+            q.lo[1] = mn3(f.v[0].y, f.v[1].y, f.v[2].y); q.hi[1] = mx3(f.v[0].y, f.v[1].y, f.v[2].y);
+            q.lo[2] = mn3(f.v[0].z, f.v[1].z, f.v[2].z); q.hi[2] = mx3(f.v[0].z, f.v[1].z, f.v[2].z);
+            for (int a = 0; a < 3; a++) {
+                if (std::isfinite(q.lo[a])) am = std::max(am, std::fabs(q.lo[a]));
+                if (std::isfinite(q.hi[a])) am = std::max(am, std::fabs(q.hi[a]));
+            }
         }
-    }
+        std::lock_guard<std::mutex> lock(amax_mu);
+        amax = std::max(amax, am);
+    });
+    if (std::getenv("MCPT_PRINT_DIAG")) std::fprintf(stderr, "fast hierarchy (host): leaf boxes %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     out.scene_absmax = amax;
     build_from_boxes(prim, kMaxLeafRt, stack_limit - 1, out);
     out.stack_limit = stack_limit;
@@ -334,11 +440,14 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
     const bool talk = std::getenv("MCPT_PRINT_DIAG") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<Vec3> cen(static_cast<size_t>(t), Vec3{});
-    for (int i = 0; i < t; i++)
-        cen[size_t(i)] = Vec3{0.5 * (prim[size_t(i)].lo[0] + prim[size_t(i)].hi[0]), 0.5 * (prim[size_t(i)].lo[1] + prim[size_t(i)].hi[1]),
-                              0.5 * (prim[size_t(i)].lo[2] + prim[size_t(i)].hi[2])};
     std::vector<int32_t> idx(static_cast<size_t>(t), 0);
-    std::iota(idx.begin(), idx.end(), 0);
+    parallel_pieces(t, [&](long long ib, long long ie) {
+        for (long long i = ib; i < ie; i++) {
+            cen[size_t(i)] = Vec3{0.5 * (prim[size_t(i)].lo[0] + prim[size_t(i)].hi[0]), 0.5 * (prim[size_t(i)].lo[1] + prim[size_t(i)].hi[1]),
+                                  0.5 * (prim[size_t(i)].lo[2] + prim[size_t(i)].hi[2])};
+            idx[size_t(i)] = int32_t(i);
+        }
+    });
     Builder bld(prim, cen, idx, out);
     bld.max_leaf = max_leaf; bld.depth_limit = budget0 + 1;
     out.nodes.reserve(size_t(t));
@@ -348,7 +457,11 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
     std::vector<Subtree> subtrees;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int workers = int(std::min(16u, hw));
-    if (t >= (1 << 17) && workers > 1 && !std::getenv("MCPT_BUILD_SERIAL")) { bld.defer = &subtrees; bld.cut = std::max(4096, t / 64); }
+    std::vector<int32_t> scratch;
+    if (t >= (1 << 17) && workers > 1 && !std::getenv("MCPT_BUILD_SERIAL")) {
+        bld.defer = &subtrees; bld.cut = std::max(4096, t / 64);
+        if (t >= Builder::kParallelMin) { scratch.resize(size_t(t)); bld.scratch = &scratch; bld.threads = workers; }
+    }
     const int32_t root = bld.build(0, t, 0);
     const auto t_top = std::chrono::steady_clock::now();
     if (talk) std::fprintf(stderr, "fast hierarchy (host): top of the tree %.2f s, %zu subtrees for %d threads\n",
@@ -356,10 +469,16 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
     if (!subtrees.empty()) {
         std::vector<FastBvh> part(subtrees.size());
         std::vector<int32_t> part_root(subtrees.size(), kFastEmpty);
+        std::vector<size_t> by_size(subtrees.size());        // largest first: the last tasks to start are the short ones
+        std::iota(by_size.begin(), by_size.end(), size_t(0));
+        std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return subtrees[x].e - subtrees[x].b > subtrees[y].e - subtrees[y].b; });
         std::atomic<size_t> next{0};
         auto work = [&]() {
-            for (size_t i = next.fetch_add(1); i < subtrees.size(); i = next.fetch_add(1)) {
+            for (size_t turn = next.fetch_add(1); turn < subtrees.size(); turn = next.fetch_add(1)) {
+                const size_t i = by_size[turn];
                 Builder wb(prim, cen, idx, part[i]);
+                part[i].nodes.reserve(size_t(subtrees[i].e - subtrees[i].b));
+                part[i].leaf_tris.reserve(size_t(subtrees[i].e - subtrees[i].b));
                 wb.max_leaf = max_leaf; wb.depth_limit = budget0 + 1;
                 part_root[i] = wb.build(subtrees[i].b, subtrees[i].e, subtrees[i].depth);
             }
@@ -369,20 +488,36 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
         work();
         for (std::thread& th : pool) th.join();
         if (talk) std::fprintf(stderr, "fast hierarchy (host): subtrees built %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_top).count());
-        for (size_t i = 0; i < subtrees.size(); i++) {
-            const int32_t node_off = int32_t(out.nodes.size()), leaf_off = int32_t(out.leaf_tris.size());
-            auto moved = [&](int32_t r) -> int32_t {
-                if (r == kFastEmpty) return r;
-                if (r >= 0) return r + node_off;
-                const int32_t v = -1 - r;
-                return -1 - ((((v >> 4) + leaf_off) << 4) | (v & 15));
-            };
-            for (FastNode nd : part[i].nodes) { nd.child[0] = moved(nd.child[0]); nd.child[1] = moved(nd.child[1]); out.nodes.push_back(nd); }
-            out.leaf_tris.insert(out.leaf_tris.end(), part[i].leaf_tris.begin(), part[i].leaf_tris.end());
-            out.nodes[size_t(subtrees[i].parent)].child[subtrees[i].slot] = moved(part_root[i]);
-            out.max_depth = std::max(out.max_depth, part[i].max_depth);
-            part[i] = FastBvh();
+        // appended in task order (so the result does not depend on timing), the copies themselves on the worker threads
+        std::vector<int32_t> node_off(subtrees.size()), leaf_off(subtrees.size());
+        {
+            size_t nn = out.nodes.size(), nl = out.leaf_tris.size();
+            for (size_t i = 0; i < subtrees.size(); i++) { node_off[i] = int32_t(nn); leaf_off[i] = int32_t(nl); nn += part[i].nodes.size(); nl += part[i].leaf_tris.size(); }
+            out.nodes.resize(nn);
+            out.leaf_tris.resize(nl);
         }
+        next = 0;
+        auto place = [&]() {
+            for (size_t i = next.fetch_add(1); i < subtrees.size(); i = next.fetch_add(1)) {
+                const int32_t no = node_off[i], lo = leaf_off[i];
+                auto moved = [&](int32_t r) -> int32_t {
+                    if (r == kFastEmpty) return r;
+                    if (r >= 0) return r + no;
+                    const int32_t v = -1 - r;
+                    return -1 - ((((v >> 4) + lo) << 4) | (v & 15));
+                };
+                FastNode* dst = out.nodes.data() + no;
+                for (FastNode nd : part[i].nodes) { nd.child[0] = moved(nd.child[0]); nd.child[1] = moved(nd.child[1]); *dst++ = nd; }
+                std::copy(part[i].leaf_tris.begin(), part[i].leaf_tris.end(), out.leaf_tris.begin() + lo);
+                out.nodes[size_t(subtrees[i].parent)].child[subtrees[i].slot] = moved(part_root[i]);     // (a node of the top part: no two tasks share a slot)
+            }
+        };
+        pool.clear();
+        for (int w = 1; w < workers; w++) pool.emplace_back(place);
+        place();
+        for (std::thread& th : pool) th.join();
+        for (size_t i = 0; i < subtrees.size(); i++) { out.max_depth = std::max(out.max_depth, part[i].max_depth); part[i] = FastBvh(); }
+        if (talk) std::fprintf(stderr, "fast hierarchy (host): subtrees in place %.2f s after the start\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     if (root < 0) {
         // a single leaf: wrap it in a root whose second child is an empty leaf with an inverted box
@@ -398,12 +533,28 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<int> height(out.nodes.size(), 0), count(out.nodes.size(), 0);
     Collapser col{out, out.cw, height, count};
+    if (!subtrees.empty()) {
+        // the subtrees the workers built, again on the workers; the pass from the root then stops at their roots
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < subtrees.size(); i = next.fetch_add(1)) {
+                const int32_t r = out.nodes[size_t(subtrees[i].parent)].child[subtrees[i].slot];
+                if (r >= 0) col.compute_height(r);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < workers; w++) pool.emplace_back(work);
+        work();
+        for (std::thread& th : pool) th.join();
+    }
     col.compute_height(0);
+    if (talk) std::fprintf(stderr, "fast hierarchy (host): heights %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     out.cw.reserve(out.nodes.size());
     std::vector<CollapseTask> ctasks;
     if (!subtrees.empty()) { col.defer = &ctasks; col.cut = std::max<int>(4096, int(out.nodes.size() / 64)); }
     int need = 0;
     col.emit(0, budget0, need);
+    if (talk) std::fprintf(stderr, "fast hierarchy (host): top of the collapse %.2f s after the heights' start, %zu tasks\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), ctasks.size());
     if (!ctasks.empty()) {
         // same scheme as the SAH pass: workers collapse whole subtrees into their own arrays, appended in task order
         std::vector<std::vector<CwNode>> part(ctasks.size());
@@ -420,16 +571,29 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
         for (int w = 1; w < workers; w++) pool.emplace_back(work);
         work();
         for (std::thread& th : pool) th.join();
-        for (size_t i = 0; i < ctasks.size(); i++) {
-            const int32_t off = int32_t(out.cw.size());
-            for (CwNode nd : part[i]) {
-                for (int c = 0; c < 4; c++) if (nd.child[c] >= 0) nd.child[c] += off;
-                out.cw.push_back(nd);
-            }
-            out.cw[size_t(ctasks[i].parent)].child[ctasks[i].slot] = off;            // a worker's root is its node 0
-            need = std::max(need, (budget0 - ctasks[i].budget) + part_need[i]);   // pushes above the subtree + below
-            std::vector<CwNode>().swap(part[i]);
+        std::vector<int32_t> off(ctasks.size());
+        {
+            size_t nn = out.cw.size();
+            for (size_t i = 0; i < ctasks.size(); i++) { off[i] = int32_t(nn); nn += part[i].size(); }
+            out.cw.resize(nn);
         }
+        next = 0;
+        auto place = [&]() {
+            for (size_t i = next.fetch_add(1); i < ctasks.size(); i = next.fetch_add(1)) {
+                CwNode* dst = out.cw.data() + off[i];
+                for (CwNode nd : part[i]) {
+                    for (int c = 0; c < 4; c++) if (nd.child[c] >= 0) nd.child[c] += off[i];
+                    *dst++ = nd;
+                }
+                out.cw[size_t(ctasks[i].parent)].child[ctasks[i].slot] = off[i];         // a worker's root is its node 0
+                std::vector<CwNode>().swap(part[i]);
+            }
+        };
+        pool.clear();
+        for (int w = 1; w < workers; w++) pool.emplace_back(place);
+        place();
+        for (std::thread& th : pool) th.join();
+        for (size_t i = 0; i < ctasks.size(); i++) need = std::max(need, (budget0 - ctasks[i].budget) + part_need[i]);   // pushes above the subtree + below
     }
     out.cw_stack_need = need;
     if (talk) {

@@ -36,8 +36,8 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
             return fail(MCPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
     } while (0)
 
-template <class T>
-int upload(const std::vector<T>& h, T** d)
+template <class T, class A>
+int upload(const std::vector<T, A>& h, T** d)
 {
     *d = nullptr;
     const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
@@ -495,6 +495,11 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     const mcpt_bvh_info bi = bvh_shape(t);
     d->bi = bi;
     int rc;
+    const bool talk = std::getenv("MCPT_PRINT_DIAG") != nullptr && t >= (1 << 17);
+    const auto t_create = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (talk) std::fprintf(stderr, "device create: %s at %.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count());
+    };
     std::vector<int32_t> order;                     // leaf -> .obj face
     const bool fast_on_device = build_mode == MCPT_BUILD_DEVICE_FAST;
     if (build_mode == MCPT_BUILD_HOST) {
@@ -526,18 +531,22 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
             return rc;
     } else {
         // faces in .obj order -> HBM, then Morton keys, stable sort, leaf records and the level-by-level union on the GPU
-        std::vector<double> v9(size_t(t) * 9), vn9(size_t(t) * 9), vt6(size_t(t) * 6), nrm3(size_t(t) * 3);
-        std::vector<int32_t> mat(t);
-        for (int i = 0; i < t; i++) {
-            const FaceRec& f = s.faces[i];
+        // (no zero fill: 2.2 GB at 10 M triangles, every element is written below)
+        std::vector<double, default_init_alloc<double>> v9(size_t(t) * 9), vn9(size_t(t) * 9), vt6(size_t(t) * 6), nrm3(size_t(t) * 3);
+        std::vector<int32_t, default_init_alloc<int32_t>> mat(static_cast<size_t>(t));
+        parallel_pieces(t, [&](long long ib, long long ie) {
+        for (long long i = ib; i < ie; i++) {
+            const FaceRec& f = s.faces[size_t(i)];
             for (int c = 0; c < 3; c++) {
                 v9[size_t(i) * 9 + c * 3] = f.v[c].x; v9[size_t(i) * 9 + c * 3 + 1] = f.v[c].y; v9[size_t(i) * 9 + c * 3 + 2] = f.v[c].z;
                 vn9[size_t(i) * 9 + c * 3] = f.vn[c].x; vn9[size_t(i) * 9 + c * 3 + 1] = f.vn[c].y; vn9[size_t(i) * 9 + c * 3 + 2] = f.vn[c].z;
                 vt6[size_t(i) * 6 + c * 2] = f.vt[c][0]; vt6[size_t(i) * 6 + c * 2 + 1] = f.vt[c][1];
             }
             nrm3[size_t(i) * 3] = f.nrm.x; nrm3[size_t(i) * 3 + 1] = f.nrm.y; nrm3[size_t(i) * 3 + 2] = f.nrm.z;
-            mat[i] = f.material;
+            mat[size_t(i)] = f.material;
         }
+        });
+        lap("faces staged");
         double *d_v9 = nullptr, *d_vn9 = nullptr, *d_vt6 = nullptr, *d_nrm3 = nullptr;
         int32_t* d_mat = nullptr;
         auto drop = [&]() { (void)hipFree(d_v9); (void)hipFree(d_vn9); (void)hipFree(d_vt6); (void)hipFree(d_nrm3); (void)hipFree(d_mat); };
@@ -557,6 +566,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("device build: ") + hipGetErrorString(e));
     }
 
+    lap("reference structures in HBM");
     std::vector<uint8_t> texels;
     std::vector<DMaterial> mats(s.materials.size());
     for (size_t i = 0; i < s.materials.size(); i++) {
@@ -599,7 +609,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     // result-identical fast structure: SAH hierarchy built on the host from the leaf order (accel_build.cpp), permuted triangle
     // copy gathered on the GPU -- or, MCPT_BUILD_DEVICE_FAST, a 4-wide tree over the Morton order built on the GPU in place
     std::shared_ptr<const FastBvh> fb_host;
-    if (!fast_on_device) fb_host = shared_fast_bvh(h, order);
+    if (!fast_on_device) { fb_host = shared_fast_bvh(h, order); lap("culling hierarchy on the host"); }
     FastBvh fb_dev;                              // MCPT_BUILD_DEVICE_FAST: shape figures of the hierarchy built on this GPU
     const FastBvh& fb_ro = fast_on_device ? fb_dev : *fb_host;
     FastBvh& fb = fb_dev;
@@ -661,6 +671,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         (void)hipFree(d_slots);
         if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("fast triangle gather: ") + hipGetErrorString(e));
     }
+    lap("culling hierarchy in HBM");
     if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
     for (auto& f : d->slot) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.ctr), sizeof(DCounters)));
