@@ -781,6 +781,8 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
                      tot ? 100.0 * c.pad[5] / tot : 0.0, tot ? 100.0 * c.pad[6] / tot : 0.0, tot ? 100.0 * c.pad[7] / tot : 0.0,
                      c.pad[0] ? double(c.pad[6]) / c.pad[0] : 0.0, c.pad[2] ? double(c.pad[7]) / c.pad[2] : 0.0);
         std::fprintf(stderr, "rays deferred to the exact walk by k_wf_trace: %llu of %llu\n", c.pad[12], c.trace_rays);
+        if (c.pad[13]) std::fprintf(stderr, "finish diag: longest wave %llu steps, %.0f us alive, %.0f us of it in the ray walks (100 MHz ticks; maxima over waves and launches)\n",
+                                    c.pad[13], double(c.pad[14]) / 100.0, double(c.pad[15]) / 100.0);
         const double lt = double(c.pad[8] + c.pad[9] + c.pad[10]);
         std::fprintf(stderr, "logic diag: resolve %.1f%% compaction %.1f%% shade %.1f%% | cycles per wave: %.0f / %.0f / %.0f (waves %llu)\n",
                      lt ? 100.0 * c.pad[8] / lt : 0.0, lt ? 100.0 * c.pad[9] / lt : 0.0, lt ? 100.0 * c.pad[10] / lt : 0.0,

@@ -374,6 +374,10 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
     bool queue_empty = false;
 
     enum { M_IDLE = 0, M_ADOPTED = 1, M_VERTEX = 2 };
+#ifdef MCPT_TRACE_DIAG
+    const unsigned long long fin_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long fin_iters = 0, fin_t_trace = 0;
+#endif
     int mode = M_IDLE;
     long long j = 0;                    // M_ADOPTED: position in the wavefront state
     int id = 0, leaf = -1, in_type = RT_TRANSMISSION;
@@ -464,6 +468,10 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
         }
         if (bt >= 0 && !(bt & MCPT_BT_NO_OFFSET)) br.o = p + br.d * 0.01;
 
+#ifdef MCPT_TRACE_DIAG
+        fin_iters++;
+        const unsigned long long fin_ta = __builtin_amdgcn_s_memtime();
+#endif
         // ---- closest hits.  One light: a lane with both rays hands its shadow ray to lane ^ 32 when that lane has no path, so
         // the two walks of a vertex run side by side -- it is the last few long paths, alone in their waves, that decide how long
         // this kernel runs.  Lanes without a free partner walk the shadow ray first and the bounce ray in a second round.
@@ -497,6 +505,9 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
             const bool second = have_b && kind == 0;
             if (__ballot(second)) { if (second) b_ok = trace_lane_fast(S, br, b_hit, w, stack, 256); }
         } else if (bt >= 0) b_ok = trace_lane_fast(S, br, b_hit, w, stack, 256);
+#ifdef MCPT_TRACE_DIAG
+        fin_t_trace += __builtin_amdgcn_s_memtime() - fin_ta;
+#endif
         if (mode == M_ADOPTED && folded) L = L + L_dir;                 // its c was stored as T * c
         else L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
 
@@ -512,6 +523,14 @@ __global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
             else { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; mode = M_IDLE; }
         }
     }
+#ifdef MCPT_TRACE_DIAG
+    if (lane == 0 && a.ctr) {
+        const unsigned long long life = __builtin_amdgcn_s_memtime() - fin_t0;
+        atomicMax(&a.ctr->pad[13], fin_iters);
+        atomicMax(&a.ctr->pad[14], life);
+        atomicMax(&a.ctr->pad[15], fin_t_trace);
+    }
+#endif
     ls.nodes += w.nodes; ls.tris += w.tris;
     flush_stats(a.ctr, ls);
 }
