@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCPT_VERSION 102
+#define MCPT_VERSION 103
 
 #define MCPT_OK             0
 #define MCPT_ERR_IO        -1   /* a scene/texture/output file could not be opened */
@@ -94,6 +94,7 @@ typedef struct {
 int         mcpt_version(void);
 const char* mcpt_last_error(void);
 int         mcpt_device_count(void);                        /* number of HIP devices (0 without a GPU) */
+const char* mcpt_build_id(void);                            /* 16 hex digits: hash of the sources this library was compiled from */
 
 /* ---- scene (host) ---- */
 /* Reads <path><filename>.obj/.mtl/.camera exactly like read_scene; textures named by map_Kd are looked up
@@ -212,6 +213,10 @@ int  mcpt_multi_num_devices(const mcpt_multi*);
 int  mcpt_multi_render(mcpt_multi*, const mcpt_render_params*, double* img, mcpt_stats* stats);
 /* the same, leaving the frame in devices[0]'s HBM: *d_img (owned by the handle, valid until the next call) */
 int  mcpt_multi_render_device(mcpt_multi*, const mcpt_render_params*, double** d_img, mcpt_stats* stats);
+/* How the last frame's time divides (HIP events on each GPU's own stream): render_ms[num_devices] = each rank's render;
+ * *gather_ms = from devices[0]'s own render being done to the last rank's pixels being in place in its HBM; *comm_ranks = the
+ * number of ranks the RCCL communicator reports (0 with MCPT_GATHER_PEER).  Any pointer may be NULL. */
+int  mcpt_multi_last_timing(const mcpt_multi*, double* render_ms, double* gather_ms, int32_t* comm_ranks);
 void mcpt_multi_free(mcpt_multi*);
 
 /* ---- output (imshow + svpng) ---- */
@@ -258,7 +263,12 @@ typedef struct {
     int32_t  gather;            /* MCPT_GATHER_* */
     const int32_t* devices;     /* NULL with num_devices > 0: ordinals 0..num_devices-1 */
 } mcpt_render_scene_options;
+/* The struct has grown with MCPT_VERSION and carries no size field.  mcpt_render_scene_ex reads only the fields every version
+ * has had (seed .. output_prefix) and ignores the rest, so a caller compiled against an older header is safe;
+ * mcpt_render_scene_opts (since 103) takes sizeof(mcpt_render_scene_options) as the caller's header defines it and reads exactly
+ * that many bytes -- the entry point for everything after output_prefix. */
 int  mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options*, mcpt_stats* stats);
+int  mcpt_render_scene_opts(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options*, int64_t options_bytes, mcpt_stats* stats);
 
 #ifdef __cplusplus
 }

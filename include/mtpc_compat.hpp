@@ -20,5 +20,5 @@ inline mcpt_render_scene_options& options()
 
 inline bool render_scene(std::string path, std::string filename, int N_ray_per_pixel)
 {
-    return mcpt_render_scene_ex(path.c_str(), filename.c_str(), N_ray_per_pixel, &mtpc::options(), nullptr) == MCPT_OK;
+    return mcpt_render_scene_opts(path.c_str(), filename.c_str(), N_ray_per_pixel, &mtpc::options(), sizeof(mcpt_render_scene_options), nullptr) == MCPT_OK;
 }

@@ -66,7 +66,7 @@ class RenderSceneOptions(C.Structure):
 
 # every symbol include/mcpt.h declares
 EXPORTS = [
-    "mcpt_version", "mcpt_last_error", "mcpt_device_count",
+    "mcpt_version", "mcpt_last_error", "mcpt_device_count", "mcpt_build_id",
     "mcpt_scene_load", "mcpt_scene_load_ex", "mcpt_scene_create", "mcpt_scene_free", "mcpt_scene_set_resolution", "mcpt_scene_get_info", "mcpt_scene_get_faces",
     "mcpt_scene_get_leaf_order", "mcpt_scene_get_bvh_nodes", "mcpt_scene_find_index", "mcpt_scene_get_material",
     "mcpt_scene_get_light", "mcpt_morton_code", "mcpt_scene_fast_bvh_stats",
@@ -76,8 +76,8 @@ EXPORTS = [
     "mcpt_render", "mcpt_render_device", "mcpt_device_collect_stats", "mcpt_sample_radiance", "mcpt_owned_pixels",
     "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_png_encode_deflate", "mcpt_write_png_deflate", "mcpt_write_pfm",
     "mcpt_checkpoint_save", "mcpt_checkpoint_load", "mcpt_decode_jpeg",
-    "mcpt_multi_create", "mcpt_multi_num_devices", "mcpt_multi_render", "mcpt_multi_render_device", "mcpt_multi_free",
-    "mcpt_render_scene", "mcpt_render_scene_ex",
+    "mcpt_multi_create", "mcpt_multi_num_devices", "mcpt_multi_render", "mcpt_multi_render_device", "mcpt_multi_last_timing", "mcpt_multi_free",
+    "mcpt_render_scene", "mcpt_render_scene_ex", "mcpt_render_scene_opts",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
     L.mcpt_version.restype = C.c_int
     L.mcpt_last_error.restype = C.c_char_p
     L.mcpt_device_count.restype = C.c_int
+    L.mcpt_build_id.restype = C.c_char_p
     L.mcpt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(P)]
     L.mcpt_scene_load_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(P)]
     L.mcpt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.POINTER(P)]
@@ -148,10 +149,12 @@ def lib():
     L.mcpt_multi_num_devices.argtypes = [P]
     L.mcpt_multi_render.argtypes = [P, C.POINTER(RenderParams), D, C.POINTER(Stats)]
     L.mcpt_multi_render_device.argtypes = [P, C.POINTER(RenderParams), C.POINTER(P), C.POINTER(Stats)]
+    L.mcpt_multi_last_timing.argtypes = [P, D, D, I32]
     L.mcpt_multi_free.argtypes = [P]
     L.mcpt_multi_free.restype = None
     L.mcpt_render_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     L.mcpt_render_scene_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(RenderSceneOptions), C.POINTER(Stats)]
+    L.mcpt_render_scene_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(RenderSceneOptions), C.c_int64, C.POINTER(Stats)]
     _lib = L
     return L
 

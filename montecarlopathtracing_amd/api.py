@@ -22,6 +22,27 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
 
+def build_id():
+    """hash of the sources libmcpt.so was compiled from (profiles/ files are stamped with it)"""
+    return lib().mcpt_build_id().decode()
+
+
+def hip_runtime_path():
+    """which libamdhip64 this process has mapped (the torch wheel bundles a copy with the same soname: whichever is loaded first is
+    the one libmcpt.so runs on)"""
+    lib()
+    found = []
+    try:
+        for ln in open("/proc/self/maps"):
+            if "libamdhip64" in ln:
+                f = ln.split()[-1]
+                if f not in found:
+                    found.append(f)
+    except OSError:
+        pass
+    return ", ".join(found) if found else "unknown"
+
+
 def device_count():
     return lib().mcpt_device_count()
 
@@ -263,6 +284,22 @@ class MultiDevice:
         check(lib().mcpt_multi_render(self._h, C.byref(rp), _p(img, C.c_double), C.byref(stats) if stats is not None else None))
         return img
 
+    def render_device(self, spp, seed=0, tile_w=0, tile_h=0, flags=0, stats=None):
+        """The frame stays in devices[0]'s HBM; returns its device address (valid until the next call)."""
+        rp = RenderParams(spp, seed, 0, 1, tile_w, tile_h, flags)
+        d_img = C.c_void_p()
+        check(lib().mcpt_multi_render_device(self._h, C.byref(rp), C.byref(d_img), C.byref(stats) if stats is not None else None))
+        return d_img.value
+
+    def last_timing(self):
+        """(render_ms per rank, gather_ms, ranks the RCCL communicator reports -- 0 with peer copies) of the last frame"""
+        n = self.num_devices
+        render_ms = np.zeros(n)
+        gather_ms = C.c_double()
+        comm = C.c_int32()
+        check(lib().mcpt_multi_last_timing(self._h, _p(render_ms, C.c_double), C.byref(gather_ms), C.byref(comm)))
+        return render_ms, gather_ms.value, comm.value
+
     def close(self):
         if getattr(self, "_h", None):
             lib().mcpt_multi_free(self._h)
@@ -361,6 +398,6 @@ def render_scene(path, filename, N_ray_per_pixel, seed=0, device=0, width=0, hei
     o = RenderSceneOptions(seed, device, width, height, int(quiet), output_prefix.encode() if output_prefix else None,
                            load_flags, output_flags, checkpoint.encode() if checkpoint else None, checkpoint_parts, 0,
                            ndev, gather, dev_arr)
-    check(lib().mcpt_render_scene_ex(path.encode(), filename.encode(), N_ray_per_pixel, C.byref(o),
-                                     C.byref(stats) if stats is not None else None))
+    check(lib().mcpt_render_scene_opts(path.encode(), filename.encode(), N_ray_per_pixel, C.byref(o), C.sizeof(o),
+                                       C.byref(stats) if stats is not None else None))
     return True

@@ -8,6 +8,7 @@
 #include <functional>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +112,12 @@ struct mcpt_device {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t look_stream = nullptr;     // the host's looks at a path count travel here, so that they wait for the logic pass that wrote
     hipEvent_t look_ev = nullptr;          // the count and for nothing enqueued after it (the finishing kernel above all)
+    unsigned int* h_look = nullptr;        // pinned host word the looks land in (never a pageable stack address: an async copy into
+                                           // pageable memory goes through the runtime's pin-on-the-fly / staging paths)
+    const mcpt_scene* scene = nullptr;     // the handle this device was created from (devices_created is given back in mcpt_device_free)
+    // closest-hit and test entry points (mcpt_trace_closest*, mcpt_sample_radiance) have counters, queue words and a deferred-ray
+    // list of their own: a frame in flight on another stream keeps using its frame slot's
+    DCounters* aux_ctr = nullptr; TraceQueue* aux_queue = nullptr; long long* aux_slow_list = nullptr;
     size_t sample_budget_bytes = size_t(4) << 30;   // megakernel path: radiance staging buffer per chunk
     size_t wf_budget_bytes = 0;                     // path state + rays per frame slot; 0 = a share of the free HBM (MCPT_WORKSPACE_GB overrides)
     size_t wf_auto_budget = 0;                      // that share, asked for once (hipMemGetInfo costs a few hundred microseconds)
@@ -451,6 +458,7 @@ void mcpt_device_free(mcpt_device* d)
 {
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
+    (void)hipDeviceSynchronize();          // frames of a sequence may still be in flight on the caller's streams
     void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes, d->d_order,
                     d->dirs, d->pixels};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -462,9 +470,12 @@ void mcpt_device_free(mcpt_device* d)
     for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pr : d->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : d->frame_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (void* p : {static_cast<void*>(d->aux_ctr), static_cast<void*>(d->aux_queue), static_cast<void*>(d->aux_slow_list)}) if (p) (void)hipFree(p);
+    if (d->h_look) (void)hipHostFree(d->h_look);
     if (d->look_stream) (void)hipStreamDestroy(d->look_stream);
     if (d->look_ev) (void)hipEventDestroy(d->look_ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->scene) d->scene->devices_created.fetch_sub(1);
     delete d;
 }
 
@@ -490,6 +501,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipStreamCreateWithFlags(&d->look_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d->look_ev, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_look), 64, hipHostMallocDefault));
 
     const int t = int(s.faces.size());
     const mcpt_bvh_info bi = bvh_shape(t);
@@ -653,7 +665,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
                 for (int c = 0; c < 4; c++)
                     if (nd.child[c] < 0 && nd.child[c] != kFastEmpty) nd.child[c] = n_up + (-1 - nd.child[c]);   // cluster -> its root node
             e = hipMalloc(reinterpret_cast<void**>(&d->cw_nodes), size_t(n_up + n_cw) * sizeof(CwNode));
-            if (e == hipSuccess) e = hipMemcpyAsync(d->cw_nodes, up.cw.data(), size_t(n_up) * sizeof(CwNode), hipMemcpyHostToDevice, d->stream);
+            if (e == hipSuccess) e = hipMemcpy(d->cw_nodes, up.cw.data(), size_t(n_up) * sizeof(CwNode), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpyAsync(d->cw_nodes + n_up, d_lower, size_t(n_cw) * sizeof(CwNode), hipMemcpyDeviceToDevice, d->stream);
             if (e == hipSuccess) e = device_offset_children(d->cw_nodes + n_up, n_cw, n_up, d->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
@@ -681,6 +693,10 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.slow_list), size_t(d->slow_cap) * sizeof(long long)));
         HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
     }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_ctr), sizeof(DCounters)));
+    HIP_TRY(hipMemset(d->aux_ctr, 0, sizeof(DCounters)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_queue), sizeof(TraceQueue)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_slow_list), size_t(d->slow_cap) * sizeof(long long)));
     if (const char* e = std::getenv("MCPT_FINISH_PATHS")) d->finish_threshold = std::atoll(e);
     init_launch_cfg(d->cfg);
     if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
@@ -714,6 +730,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     d->width = s.width; d->height = s.height;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->dirs), size_t(s.width) * s.height * 3 * sizeof(double)));
     h->devices_created.fetch_add(1);
+    d->scene = h;
     *out = d.release();
     return MCPT_OK;
 }
@@ -797,7 +814,7 @@ int mcpt_trace_closest_device(mcpt_device* d, const double* d_rays, int64_t n, i
     if (!d || (n > 0 && !d_rays) || n < 0) return fail(MCPT_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(d->ordinal));
     if (!d_face || !d_t || !d_p) return fail(MCPT_ERR_ARG, "d_face, d_t and d_p are required by the device form");
-    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->slot[0].ctr, d->slot[0].queue, d->slot[0].slow_list, d->slow_cap,
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->aux_ctr, d->aux_queue, d->aux_slow_list, d->slow_cap,
                          static_cast<hipStream_t>(stream), d->cfg);
     HIP_TRY(hipGetLastError());
     return MCPT_OK;
@@ -818,19 +835,20 @@ int mcpt_trace_closest(mcpt_device* d, const double* rays, int64_t n, int32_t* f
     TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_t), size_t(n) * sizeof(double)));
     TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_p), size_t(n) * 3 * sizeof(double)));
     TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_pn), size_t(n) * 3 * sizeof(double)));
-    TRY_OR_CLEAN(hipMemcpyAsync(d_rays, rays, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice, d->stream));
-    TRY_OR_CLEAN(hipMemsetAsync(d->slot[0].ctr, 0, sizeof(DCounters), d->stream));
+    // host buffers are pageable: blocking copies (the runtime stages them), ordered around the kernels by stream synchronisation
+    TRY_OR_CLEAN(hipMemcpy(d_rays, rays, size_t(n) * 6 * sizeof(double), hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemsetAsync(d->aux_ctr, 0, sizeof(DCounters), d->stream));
     TRY_OR_CLEAN(hipEventRecord(d->ev[0], d->stream));
-    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->slot[0].ctr, d->slot[0].queue, d->slot[0].slow_list, d->slow_cap, d->stream, d->cfg);
+    launch_trace_closest(d->ds, d->trace_mode == MCPT_TRACE_FAST, d_rays, n, d_face, d_t, d_p, d_pn, d->aux_ctr, d->aux_queue, d->aux_slow_list, d->slow_cap, d->stream, d->cfg);
     TRY_OR_CLEAN(hipGetLastError());
     TRY_OR_CLEAN(hipEventRecord(d->ev[1], d->stream));
-    if (face) TRY_OR_CLEAN(hipMemcpyAsync(face, d_face, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-    if (t) TRY_OR_CLEAN(hipMemcpyAsync(t, d_t, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-    if (p) TRY_OR_CLEAN(hipMemcpyAsync(p, d_p, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-    if (pn) TRY_OR_CLEAN(hipMemcpyAsync(pn, d_pn, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-    DCounters c{};
-    TRY_OR_CLEAN(hipMemcpyAsync(&c, d->slot[0].ctr, sizeof c, hipMemcpyDeviceToHost, d->stream));
     TRY_OR_CLEAN(hipStreamSynchronize(d->stream));
+    if (face) TRY_OR_CLEAN(hipMemcpy(face, d_face, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (t) TRY_OR_CLEAN(hipMemcpy(t, d_t, size_t(n) * sizeof(double), hipMemcpyDeviceToHost));
+    if (p) TRY_OR_CLEAN(hipMemcpy(p, d_p, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (pn) TRY_OR_CLEAN(hipMemcpy(pn, d_pn, size_t(n) * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    DCounters c{};
+    TRY_OR_CLEAN(hipMemcpy(&c, d->aux_ctr, sizeof c, hipMemcpyDeviceToHost));
     if (stats) {
         counters_to_stats(c, stats);
         float ms = 0;
@@ -857,10 +875,7 @@ static int prepare_partition(mcpt_device* d, const mcpt_render_params* p, hipStr
         (void)hipFree(d->pixels); d->pixels = nullptr;
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->pixels), std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
-    if (!v.empty()) {
-        HIP_TRY(hipMemcpyAsync(d->pixels, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));     // v goes out of scope
-    }
+    if (!v.empty()) HIP_TRY(hipMemcpy(d->pixels, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));   // blocking: v is pageable
     d->n_pixels = int64_t(v.size());
     std::memcpy(d->part_key, key, sizeof key);
     return MCPT_OK;
@@ -996,11 +1011,11 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
             // finishing kernel is launched and the call returns while it runs -- the next frame's head can overlap it.
             const bool look = (depth + 1) % kSyncEvery == 0 || (a.finish_below && n_grid * 0.6 <= 6.0 * double(a.finish_below));
             if (look) {
-                unsigned int n_now = 0;
                 HIP_TRY(hipEventRecord(d->look_ev, st));
                 HIP_TRY(hipStreamWaitEvent(d->look_stream, d->look_ev, 0));
-                HIP_TRY(hipMemcpyAsync(&n_now, &f.wf_counts[depth + 1].n_next, sizeof n_now, hipMemcpyDeviceToHost, d->look_stream));
+                HIP_TRY(hipMemcpyAsync(d->h_look, &f.wf_counts[depth + 1].n_next, sizeof(unsigned int), hipMemcpyDeviceToHost, d->look_stream));
                 HIP_TRY(hipStreamSynchronize(d->look_stream));
+                const unsigned int n_now = *d->h_look;
                 if (n_now <= a.finish_below) {
                     if (n_now > 0) { launch_wf_finish(d->ds, a, (long long)n_now, st, d->cfg); HIP_TRY(hipGetLastError()); }
                     n_upper = 0;
@@ -1045,12 +1060,26 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
     return MCPT_OK;
 }
 
+static int render_device_impl(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, hipStream_t st, int& slot_used);
+
 int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, void* stream)
 {
     if (!d || !p || !d_img || p->spp <= 0) return fail(MCPT_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(d->ordinal));
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (stats) std::memset(stats, 0, sizeof *stats);
+    // a frame that fails half-way must not leave half-recorded event pairs behind: mcpt_device_collect_stats would trip over them
+    const size_t ev_used0 = d->ev_used, frame_ev_used0 = d->frame_ev_used;
+    int slot_used = -1;
+    const int rc = render_device_impl(d, p, d_img, stats, static_cast<hipStream_t>(stream), slot_used);
+    if (rc != MCPT_OK) {
+        d->ev_used = ev_used0; d->frame_ev_used = frame_ev_used0;
+        if (slot_used >= 0) d->slot[slot_used].keeping = false;      // its counters hold part of a frame: cleared by the next one
+    }
+    return rc;
+}
+
+static int render_device_impl(mcpt_device* d, const mcpt_render_params* p, double* d_img, mcpt_stats* stats, hipStream_t st, int& slot_used)
+{
     const bool keep = (p->flags & MCPT_RENDER_KEEP_STATS) != 0 && !(p->flags & MCPT_RENDER_MEGAKERNEL);
     const bool timed = stats != nullptr && !keep;
     // frame slot: consecutive pipelined frames alternate; a slot's previous frame (possibly on another stream) must be over
@@ -1060,6 +1089,7 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
         for (auto& q : d->slot) { if (q.wf_ws) (void)hipFree(q.wf_ws); q.wf_ws = nullptr; q.wf_ws_bytes = 0; }
     }
     const int si = (p->flags & MCPT_RENDER_PIPELINE) ? (d->next_slot ^= 1) : 0;
+    slot_used = si;
     mcpt_device::FrameSlot& f = d->slot[si];
     if (f.used) HIP_TRY(hipStreamWaitEvent(st, f.done, 0));
     int rc = ensure_dirs(d, st);
@@ -1097,8 +1127,8 @@ int mcpt_render_device(mcpt_device* d, const mcpt_render_params* p, double* d_im
     f.used = true;
     if (timed) {
         DCounters c{};
-        HIP_TRY(hipMemcpyAsync(&c, f.ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(&c, f.ctr, sizeof c, hipMemcpyDeviceToHost));
         counters_to_stats(c, stats);
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
@@ -1129,18 +1159,22 @@ int mcpt_device_collect_stats(mcpt_device* d, mcpt_stats* stats)
         sum.max_depth = std::max(sum.max_depth - c.max_depth, c.max_depth);      // a maximum, not a sum
     }
     counters_to_stats(sum, stats);
+    // the bookkeeping starts over whatever the queries say: a pair that cannot be read is left out and reported
+    hipError_t bad = hipSuccess;
     for (size_t i = 0; i < d->ev_used; i++) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, d->ev_pool[i].first, d->ev_pool[i].second));
-        stats->ms_trace += ms;
+        const hipError_t e = hipEventElapsedTime(&ms, d->ev_pool[i].first, d->ev_pool[i].second);
+        if (e == hipSuccess) stats->ms_trace += ms; else bad = e;
     }
     for (size_t i = 0; i < d->frame_ev_used; i++) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, d->frame_ev[i].first, d->frame_ev[i].second));
-        stats->ms_total += ms;
+        const hipError_t e = hipEventElapsedTime(&ms, d->frame_ev[i].first, d->frame_ev[i].second);
+        if (e == hipSuccess) stats->ms_total += ms; else bad = e;
     }
     stats->launches = d->kept_launches; stats->samples = d->kept_samples; stats->rays_primary = d->kept_primary;
     d->ev_used = 0; d->frame_ev_used = 0; d->kept_launches = 0; d->kept_samples = 0; d->kept_primary = 0;
+    for (auto& f : d->slot) f.keeping = false;
+    if (bad != hipSuccess) { (void)hipGetLastError(); return fail(MCPT_ERR_HIP, std::string("an event pair of a kept frame could not be read: ") + hipGetErrorString(bad)); }
     return MCPT_OK;
 }
 
@@ -1151,13 +1185,13 @@ int mcpt_render(mcpt_device* d, const mcpt_render_params* p, double* img, mcpt_s
     const size_t bytes = size_t(d->width) * d->height * 3 * sizeof(double);
     double* d_img = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_img), bytes));
-    hipError_t e = hipMemcpyAsync(d_img, img, bytes, hipMemcpyHostToDevice, d->stream);   // untouched pixels keep the caller's values
+    // The caller's frame is pageable host memory: blocking copies on either side of the frame, which itself is ordered on d->stream.
+    hipError_t e = hipMemcpy(d_img, img, bytes, hipMemcpyHostToDevice);   // untouched pixels keep the caller's values
     int rc = e == hipSuccess ? mcpt_render_device(d, p, d_img, stats, d->stream) : fail(MCPT_ERR_HIP, hipGetErrorString(e));
-    if (rc == MCPT_OK) {
-        e = hipMemcpyAsync(img, d_img, bytes, hipMemcpyDeviceToHost, d->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-        if (e != hipSuccess) rc = fail(MCPT_ERR_HIP, hipGetErrorString(e));
-    }
+    // also on failure: nothing of this frame may still be running when d_img goes
+    e = hipStreamSynchronize(d->stream);
+    if (rc == MCPT_OK && e == hipSuccess) e = hipMemcpy(img, d_img, bytes, hipMemcpyDeviceToHost);
+    if (rc == MCPT_OK && e != hipSuccess) rc = fail(MCPT_ERR_HIP, hipGetErrorString(e));
     (void)hipFree(d_img);
     return rc;
 }
@@ -1177,14 +1211,14 @@ int mcpt_sample_radiance(mcpt_device* d, uint64_t seed, const int32_t* pix, cons
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_pix), size_t(n) * 4);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_k), size_t(n) * 4);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rgb), size_t(n) * 24);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pix, pix, size_t(n) * 4, hipMemcpyHostToDevice, d->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_k, k, size_t(n) * 4, hipMemcpyHostToDevice, d->stream);
+    if (e == hipSuccess) e = hipMemcpy(d_pix, pix, size_t(n) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_k, k, size_t(n) * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        launch_sample_radiance(d->ds, seed, d->dirs, d_pix, d_k, n, d_rgb, d->slot[0].ctr, d->stream);
+        launch_sample_radiance(d->ds, seed, d->dirs, d_pix, d_k, n, d_rgb, d->aux_ctr, d->stream);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_rgb, size_t(n) * 24, hipMemcpyDeviceToHost, d->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess) e = hipMemcpy(rgb, d_rgb, size_t(n) * 24, hipMemcpyDeviceToHost);
     cleanup();
     if (e != hipSuccess) return fail(MCPT_ERR_HIP, hipGetErrorString(e));
     return MCPT_OK;
@@ -1312,11 +1346,19 @@ int mcpt_decode_jpeg(const char* file, int32_t* width, int32_t* height, uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------------ render_scene
+// The options struct has grown with the library version and carries no size of its own: mcpt_render_scene_ex reads the fields
+// every version has had (through output_prefix, MCPT_VERSION 100) and nothing behind them -- a caller built against an older
+// header hands over a shorter struct -- and mcpt_render_scene_opts takes the caller's sizeof and reads that many bytes.
 int mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options* opt, mcpt_stats* stats)
 {
-    if (!path || !filename || spp <= 0) return fail(MCPT_ERR_ARG, "bad argument");
+    return mcpt_render_scene_opts(path, filename, spp, opt, opt ? int64_t(offsetof(mcpt_render_scene_options, load_flags)) : 0, stats);
+}
+
+int mcpt_render_scene_opts(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options* opt, int64_t opt_bytes, mcpt_stats* stats)
+{
+    if (!path || !filename || spp <= 0 || opt_bytes < 0 || (opt_bytes > 0 && !opt)) return fail(MCPT_ERR_ARG, "bad argument");
     mcpt_render_scene_options o{};
-    if (opt) o = *opt;
+    if (opt) std::memcpy(&o, opt, std::min<size_t>(size_t(opt_bytes), sizeof o));
     const bool talk = !o.quiet;
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();

@@ -9,8 +9,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,6 +30,7 @@ struct RcclApi {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -42,6 +46,7 @@ struct RcclApi {
         auto sym = [&](const char* n) { return dlsym(lib, n); };
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
@@ -66,6 +71,62 @@ struct Rank {
     mcpt_stats stats{};
     int rc = MCPT_OK;
     std::string err;
+    hipEvent_t ev_start = nullptr, ev_rendered = nullptr;   // on the rank's stream: before its render / after its render (timing report)
+    float render_ms = 0;
+};
+
+// One long-lived host thread per GPU (ranks 1..n-1; rank 0 works on the caller's thread): a frame hands each of them one job and
+// waits for all.  Threads started per frame would pay their creation and the runtime's per-thread set-up inside every frame.
+struct Workers {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<void(int)> job;
+    uint64_t generation = 0;
+    int pending = 0;
+    bool quit = false;
+    std::vector<std::thread> threads;
+
+    void start(int n_ranks)
+    {
+        for (int r = 1; r < n_ranks; r++)
+            threads.emplace_back([this, r]() {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::function<void(int)> fn;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_job.wait(lk, [&] { return quit || generation != seen; });
+                        if (quit) return;
+                        seen = generation;
+                        fn = job;
+                    }
+                    fn(r);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    // fn(r) for every rank; rank 0 on the calling thread
+    void run(const std::function<void(int)>& fn)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = fn; pending = int(threads.size()); generation++;
+        }
+        cv_job.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_job.notify_all();
+        for (std::thread& t : threads) t.join();
+        threads.clear();
+    }
 };
 
 }  // namespace
@@ -74,11 +135,13 @@ struct mcpt_multi {
     const mcpt_scene* scene = nullptr;
     int width = 0, height = 0;
     int gather = MCPT_GATHER_PEER;
-    int part_key[2] = {0, 0};           // tile shape the pixel lists were made for
+    int part_key[2] = {-1, -1};         // tile shape the pixel lists were made for ({-1,-1}: none)
     std::vector<Rank> ranks;
     RcclApi rccl;
     std::vector<ncclComm_t> comms;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_gather = nullptr;   // on devices[0]'s stream: frame start, frame end, its own render done
+    float gather_ms = 0;                // last frame: from rank 0's render being done to the last unpack (what the exchange adds)
+    Workers workers;
 };
 
 #define HIP_OR_FAIL(expr)                                                                               \
@@ -106,6 +169,7 @@ static int prepare_lists(mcpt_multi* m, const mcpt_render_params* p)
     const int key[2] = {p->tile_w, p->tile_h};
     if (m->ranks[0].d_pixels && std::memcmp(key, m->part_key, sizeof key) == 0) return MCPT_OK;
     free_lists(m);
+    m->part_key[0] = m->part_key[1] = -1;       // whatever fails below, no list of this handle counts as valid
     const int world = int(m->ranks.size());
     for (int r = 0; r < world; r++) {
         Rank& R = m->ranks[size_t(r)];
@@ -137,17 +201,21 @@ extern "C" {
 void mcpt_multi_free(mcpt_multi* m)
 {
     if (!m) return;
+    m->workers.stop();
     if (!m->ranks.empty()) free_lists(m);
     for (size_t i = 0; i < m->comms.size(); i++)
         if (m->comms[i] && m->rccl.CommDestroy) { (void)hipSetDevice(m->ranks[i].ordinal); (void)m->rccl.CommDestroy(m->comms[i]); }
     for (Rank& r : m->ranks) {
         (void)hipSetDevice(r.ordinal);
         if (r.d_frame) (void)hipFree(r.d_frame);
+        if (r.ev_start) (void)hipEventDestroy(r.ev_start);
+        if (r.ev_rendered) (void)hipEventDestroy(r.ev_rendered);
         if (r.stream) (void)hipStreamDestroy(r.stream);
         if (r.dev) mcpt_device_free(r.dev);
     }
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->ev_gather) (void)hipEventDestroy(m->ev_gather);
     if (m->rccl.lib) dlclose(m->rccl.lib);
     delete m;
 }
@@ -188,6 +256,8 @@ int mcpt_multi_create(const mcpt_scene* scene, const int32_t* devices, int32_t n
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&R.d_frame), frame_bytes);
         if (e == hipSuccess) e = hipMemset(R.d_frame, 0, frame_bytes);
+        if (e == hipSuccess) e = hipEventCreate(&R.ev_start);
+        if (e == hipSuccess) e = hipEventCreate(&R.ev_rendered);
         if (e != hipSuccess) { R.rc = MCPT_ERR_HIP; R.err = std::string("multi-device setup: ") + hipGetErrorString(e); }
     };
     {
@@ -211,6 +281,8 @@ int mcpt_multi_create(const mcpt_scene* scene, const int32_t* devices, int32_t n
     HIP_OR_FAIL(hipSetDevice(m->ranks[0].ordinal));
     HIP_OR_FAIL(hipEventCreate(&m->ev0));
     HIP_OR_FAIL(hipEventCreate(&m->ev1));
+    HIP_OR_FAIL(hipEventCreate(&m->ev_gather));
+    m->workers.start(int(m->ranks.size()));
     if (gather == MCPT_GATHER_RCCL) {
         std::string err;
         if (!m->rccl.load(err)) return fail(MCPT_ERR_IO, err);
@@ -240,9 +312,15 @@ int mcpt_multi_render_device(mcpt_multi* m, const mcpt_render_params* p, double*
         Rank& R = m->ranks[size_t(r)];
         mcpt_render_params q = *p;
         q.rank = r; q.world = world;
+        R.rc = MCPT_OK; R.err.clear();
+        hipError_t e = hipSetDevice(R.ordinal);
+        if (e == hipSuccess) e = hipEventRecord(R.ev_start, R.stream);
+        if (e != hipSuccess) { R.rc = MCPT_ERR_HIP; R.err = std::string("multi-device render: ") + hipGetErrorString(e); return; }
         R.rc = mcpt_render_device(R.dev, &q, R.d_frame, &R.stats, R.stream);
         if (R.rc) { R.err = mcpt_last_error(); return; }
-        hipError_t e = hipSetDevice(R.ordinal);
+        e = hipSetDevice(R.ordinal);
+        if (e == hipSuccess) e = hipEventRecord(R.ev_rendered, R.stream);
+        if (e == hipSuccess && r == 0) e = hipEventRecord(m->ev_gather, R.stream);
         if (e == hipSuccess && r > 0 && R.n > 0) {
             mcpt::launch_pack_pixels(R.d_frame, R.d_pixels, R.n, R.d_compact, R.stream);
             e = hipGetLastError();
@@ -252,12 +330,7 @@ int mcpt_multi_render_device(mcpt_multi* m, const mcpt_render_params* p, double*
         if (e == hipSuccess && !rccl) e = hipStreamSynchronize(R.stream);
         if (e != hipSuccess) { R.rc = MCPT_ERR_HIP; R.err = std::string("multi-device render: ") + hipGetErrorString(e); }
     };
-    {
-        std::vector<std::thread> pool;
-        for (int r = 1; r < world; r++) pool.emplace_back(work, r);
-        work(0);
-        for (std::thread& t : pool) t.join();
-    }
+    m->workers.run(work);
     for (Rank& R : m->ranks) if (R.rc) return fail(R.rc, R.err);
     if (rccl) {
         // every rank's send and rank 0's receives as ONE group: each send is ordered after the rank's render + pack on its stream,
@@ -297,7 +370,32 @@ int mcpt_multi_render_device(mcpt_multi* m, const mcpt_render_params* p, double*
         (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);      // rank 0's stream from before its render to after the last unpack
         stats->ms_total = ms;
     }
+    m->gather_ms = 0;
+    (void)hipEventElapsedTime(&m->gather_ms, m->ev_gather, m->ev1);
+    for (Rank& R : m->ranks) {
+        R.render_ms = 0;
+        (void)hipSetDevice(R.ordinal);
+        if (hipEventSynchronize(R.ev_rendered) == hipSuccess) (void)hipEventElapsedTime(&R.render_ms, R.ev_start, R.ev_rendered);
+    }
+    (void)hipGetLastError();
+    (void)hipSetDevice(R0.ordinal);
     *d_img = R0.d_frame;
+    return MCPT_OK;
+}
+
+// what the last frame's parts took (HIP events on each rank's own stream): render_ms[num_devices] (may be NULL), *gather_ms (may
+// be NULL) = from devices[0]'s own render being done to the last rank's pixels being in place; *comm_ranks (may be NULL) = ranks the
+// RCCL communicator reports (0 with MCPT_GATHER_PEER)
+int mcpt_multi_last_timing(const mcpt_multi* m, double* render_ms, double* gather_ms, int32_t* comm_ranks)
+{
+    if (!m) return fail(MCPT_ERR_ARG, "null handle");
+    if (render_ms) for (size_t i = 0; i < m->ranks.size(); i++) render_ms[i] = m->ranks[i].render_ms;
+    if (gather_ms) *gather_ms = m->gather_ms;
+    if (comm_ranks) {
+        int n = 0;
+        if (!m->comms.empty() && m->comms[0] && m->rccl.CommCount) (void)m->rccl.CommCount(m->comms[0], &n);
+        *comm_ranks = n;
+    }
     return MCPT_OK;
 }
 

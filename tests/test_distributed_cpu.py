@@ -1,18 +1,22 @@
-"""Not gpu: the N>1 path of bench.py / dist.py with world_size 2 on the gloo backend.  The tiles come from the CPU oracle
-(test infrastructure) so that the partition + gather + scatter assembly is checked end to end without a GPU."""
+"""Not gpu: the one-process-per-GPU launcher form of the N>1 path (bench.py --launcher torch / dist.py) with world_size 2 on the
+gloo backend.  The tiles come from the CPU oracle (test infrastructure) so that the partition + gather + scatter assembly is
+checked end to end without a GPU.
+
+torch is imported inside the functions, not at module level: pytest imports every test module while collecting, also under
+`-m gpu`, and the torch wheel bundles its own copy of the HIP runtime (same soname as /opt/rocm's) -- imported first, it is the
+runtime libmcpt.so would then run on.  The GPU tests run on the runtime libmcpt.so was built against."""
 import os
 import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from conftest import ROOT, SCENES
 
 
 def _worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -45,6 +49,7 @@ def _worker(rank, world, port, tmp):
 
 @pytest.mark.parametrize("world", [2])
 def test_gather_assembles_the_frame(world, tmp_path):
+    import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     frame = np.load(tmp_path / "frame.npy")

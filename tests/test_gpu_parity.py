@@ -483,11 +483,15 @@ def test_multi_device_frame_equals_single_device(mcpt):
         assert (st.rays_shadow + st.shadow_skipped, st.rays_bounce, st.shade_calls) == (st1.rays_shadow + st1.shadow_skipped, st1.rays_bounce, st1.shade_calls)
     md = mcpt.MultiDevice(sc, list(range(mcpt.device_count())), gather=mcpt.GATHER_RCCL)
     assert np.array_equal(_bits(md.generateImg(8, seed=5)), _bits(want))
+    render_ms, gather_ms, comm_ranks = md.last_timing()
+    assert comm_ranks == mcpt.device_count() and len(render_ms) == md.num_devices and render_ms.min() > 0 and gather_ms >= 0
+    with pytest.raises(mcpt.McptError):
+        sc.set_resolution(100, 60)                                     # a device created from this scene is alive
     md.close()
     with pytest.raises(mcpt.McptError):
         mcpt.MultiDevice(sc, [0, 0], gather=mcpt.GATHER_RCCL)          # RCCL wants distinct GPUs
-    with pytest.raises(mcpt.McptError):
-        sc.set_resolution(100, 60)                                     # a device was created from this scene
+    sc.set_resolution(100, 60)                                         # every device is gone again: the camera may change
+    assert (sc.info.width, sc.info.height) == (100, 60)
     sc.close()
 
 
@@ -646,23 +650,106 @@ def test_bench_line_keeps_its_contract(tmp_path):
     assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["scaling"] in ("strong", "weak")
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    # the plain form drives the product's own multi-GPU entry (mcpt_multi_*, RCCL communicator of one here), one frame at a time,
+    # in a process that has not loaded torch's copy of the HIP runtime
+    assert d["config"]["launcher"].startswith("capi") and d["config"]["frames_in_flight"] == 1 and d["latency_ms_per_frame"] == d["ms_per_step"]
+    assert d["rccl_ranks"] == 1 and d["gather"] == "rccl" and len(d["per_rank_render_ms"]) == 1 and "torch" not in d["hip_runtime"]
+    assert len(d["build_id"]) == 16
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert (r["bytes_per_unit"]["node_visit"], r["bytes_per_unit"]["triangle_test"], r["bytes_per_unit"]["ray"]) == (32, 48, 64)
-    assert r["record_bytes_rate_GBs"] > r["achieved"] and r["traffic"] is None      # not the headline workload: nothing measured to quote
+    assert r["record_bytes_rate_GBs"] > r["achieved"] and r["traffic"] is None and "not the headline workload" in r["traffic_source"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
 
 
+def test_bench_refuses_more_gpus_than_visible_and_quotes_only_profiles_of_the_loaded_build(mcpt, tmp_path):
+    """`python bench.py --gpus N` without a launcher needs N visible GPUs (exit code 2, nothing on stdout).  Counters quoted from
+    profiles/ must come from the build that is loaded: committed_profile() matches the file's build_id against mcpt_build_id()."""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    n = mcpt.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 2 and not out.stdout.strip() and "visible" in out.stderr
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r09_final_hbm_traffic.json").write_text(json.dumps({"bytes_per_launch": 1.0, "build_id": "0123456789abcdef"}))
+    old_root = bench.ROOT
+    bench.ROOT = str(tmp_path)
+    try:
+        f, j, why = bench.committed_profile("r*_final_hbm_traffic.json", mcpt.build_id())
+        assert f is None and j is None and "another build" in why
+        f, j, why = bench.committed_profile("r*_final_hbm_traffic.json", "0123456789abcdef")
+        assert j["bytes_per_launch"] == 1.0 and why is None
+    finally:
+        bench.ROOT = old_root
+
+
+def _oracle_pixels_of_full_frame(oracle, prefix, texture_dir, spp, seed, full, name):
+    """A BASELINE frame at its own size and SPP against the oracle where the oracle can follow in seconds: a 64x36-pixel crop
+    around the frame's centre and 2 000 pixels drawn at random, every one at the full SPP (a pixel is the float fold of its spp
+    samples in order on both sides, so a pixel either agrees to the accumulator's rounding or holds a flipped sample)."""
+    osc = oracle.OracleScene(prefix, texture_dir=texture_dir)
+    H, W = osc.height, osc.width
+    assert full.shape == (H, W, 3)
+    ref = np.zeros((H, W, 3))
+    r0, c0 = H // 2 - 18, W // 2 - 32
+    osc.render(spp, seed=seed, rows=(r0, r0 + 36), cols=(c0, c0 + 64), img=ref)
+    mask = np.zeros((H, W), dtype=bool)
+    mask[r0:r0 + 36, c0:c0 + 64] = True
+    rng = np.random.default_rng(2024)
+    for pix in rng.choice(H * W, size=2000, replace=False):
+        r, c = divmod(int(pix), W)
+        if not mask[r, c]:
+            osc.render(spp, seed=seed, rows=(r, r + 1), cols=(c, c + 1), img=ref)
+            mask[r, c] = True
+    osc.close()
+    got, want = full[mask], ref[mask]
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-6)
+    bad = int((rel > 1e-6).sum())
+    budget = max(3, int(got.size * spp * FLIP_BUDGET[name]))       # channels x samples per pixel x flips per sample
+    assert bad <= budget, "%s: %d of %d pixel channels differ from the oracle (max rel %.3e)" % (name, bad, got.size, rel.max())
+    assert want.mean() > 0 and abs(got.mean() - want.mean()) <= (2e-3 + 25 * FLIP_BUDGET[name]) * want.mean()
+    return int(mask.sum()), bad
+
+
+def test_config1_workload_on_the_gpu(mcpt, oracle):
+    """BASELINE config 1's workload -- cornell-box 400x400 SPP 2, the reference's own CPU-runnable case -- whole image, HIP path
+    against the oracle."""
+    import bench
+    d = bench.write_scene_dir("cornell-box", 400, 400)
+    sc = mcpt.Scene(d, "cornell-box")
+    dev = mcpt.Device(sc, 0)
+    st = mcpt.Stats()
+    img = dev.generateImg(2, seed=0, stats=st)
+    osc = oracle.OracleScene(d + "cornell-box", texture_dir=d)
+    ost = oracle.Stats()
+    ref = osc.render(2, seed=0, stats=ost)
+    rel = np.abs(img - ref) / np.maximum(np.abs(ref), 1e-6)
+    bad = int((rel > 1e-6).sum())
+    assert bad <= max(3, int(img.size * 2 * FLIP_BUDGET["cornell-box"])), "%d pixel channels differ (max rel %.3e)" % (bad, rel.max())
+    assert st.samples == ost.samples == 400 * 400 * 2
+    assert st.rays_shadow + st.shadow_skipped == ost.rays_shadow and st.rays_bounce == ost.rays_bounce and st.shade_calls == ost.shade_calls
+    assert int((mcpt.imshow_rgb8(img) != oracle.quantize(ref)).sum()) <= 8
+    osc.close(); dev.close(); sc.close()
+
+
 @pytest.mark.parametrize("name,spp", [("cornell-box", 256), ("veach-mis", 100), ("interior", 256)])
-def test_full_size_frame_properties(mcpt, monkeypatch, name, spp, tmp_path):
+def test_full_size_frame_properties(mcpt, oracle, monkeypatch, name, spp, tmp_path):
     """BASELINE's own frames (configs 2, 3 and 4: cornell-box 1280x720 SPP 256, veach-mis SPP 100, and the generated textured
     interior of 204 k triangles that stands in for the unshipped bedroom scene, SPP 256), which the oracle cannot finish in
     seconds, through properties that do
     not depend on size: rendering it again gives the same bits; the 8-rank tile partition assembles to the same bits; a frame
     cut into chunks by a small workspace gives the same bits; its mean agrees with an independent seed's within Monte-Carlo
-    error; every ray the statistics count was traced (samples = pixels x SPP, rays = shadow + bounce)."""
+    error; every ray the statistics count was traced (samples = pixels x SPP, rays = shadow + bounce).  And directly against the
+    oracle where it can follow: a 64x36 crop and 2 000 random pixels at the full SPP (_oracle_pixels_of_full_frame)."""
     import bench
     if name == "interior":
         from montecarlopathtracing_amd import synthetic
@@ -679,6 +766,8 @@ def test_full_size_frame_properties(mcpt, monkeypatch, name, spp, tmp_path):
     full = dev.generateImg(spp, seed=0, stats=st)
     again = dev.generateImg(spp, seed=0)
     assert np.array_equal(_bits(full), _bits(again))
+    n_pix, n_bad = _oracle_pixels_of_full_frame(oracle, d + name, d, spp, 0, full, name)       # held to the oracle at full size and SPP
+    print("%s 1280x720 SPP %d: %d pixels against the oracle, %d channels outside 1e-6" % (name, spp, n_pix, n_bad))
     assert st.samples == 1280 * 720 * spp and st.rays_primary == 1280 * 720
     assert st.rays_shadow > 0 and st.rays_bounce > 0 and st.shade_calls >= st.rays_bounce * 0.9
     parts = np.zeros_like(full)
