@@ -370,6 +370,12 @@ def main():
     ap.add_argument("--sim-rank", type=int, default=0, help="with --sim-world: which rank's tiles")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: libraries that print banners to file descriptor 1 (RCCL's version block, Gloo's connection chatter)
+    # are sent to stderr for the length of the run; the line itself goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     launcher = args.launcher
     if launcher == "auto":
         launcher = "torch" if int(os.environ.get("WORLD_SIZE", "0")) >= 1 and "RANK" in os.environ else "capi"
@@ -462,6 +468,8 @@ def main():
                                        "where the port does 1.2).  It traces the reference's 2.7 rays per sample, the GPU 1.6 (primary ray once per pixel, unused "
                                        "shadow rays skipped): compare frame times (gpu_over_cpu_frame_time), not Mrays/s")
     sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     print(json.dumps(out), flush=True)
 
 

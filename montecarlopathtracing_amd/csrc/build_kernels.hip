@@ -333,6 +333,38 @@ hipError_t device_build_reference(const BuildInputs& in, const mcpt_bvh_info& bi
     return rc;
 }
 
+// fp32 records of the triangle phase's pre-test (device_scene.hpp: DTriPre, trace_fast.hpp: tri_pre_reject), one per slot of the
+// fast triangle array.  Edges are differenced in fp64 and rounded once; a1, a2 are rounded up.  a1 = +inf (pre-test off) when
+// the error analysis of the test does not cover the triangle: a non-finite coordinate, a shortest edge below 2^-16 of the
+// scene's largest coordinate, or a sliver whose shortest edge is below 2^-12 of its longest.
+__global__ void k_build_pre(const DTri* __restrict__ tris, int n, double absmax, DTriPre* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DTri* t = tris + i;
+    const double e1[3] = {t->v2[0] - t->v1[0], t->v2[1] - t->v1[1], t->v2[2] - t->v1[2]};
+    const double e2[3] = {t->v3[0] - t->v1[0], t->v3[1] - t->v1[1], t->v3[2] - t->v1[2]};
+    const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
+    auto len = [](const double* e) { return sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]); };
+    const double l1 = len(e1), l2 = len(e2), l3 = len(e3);
+    const double lmin = fmin(l1, fmin(l2, l3)), lmax = fmax(l1, fmax(l2, l3));
+    DTriPre q;
+    for (int a = 0; a < 3; a++) { q.v0[a] = (float)t->v1[a]; q.e1[a] = (float)e1[a]; q.e2[a] = (float)e2[a]; }
+    // 1-norms of the fp32 edges and of the true ones (the two differ by 2^-24 relative): rounded up with room to spare
+    q.a1 = __double2float_ru((fabs(e1[0]) + fabs(e1[1]) + fabs(e1[2])) * (1.0 + 0x1p-20));
+    q.a2 = __double2float_ru((fabs(e2[0]) + fabs(e2[1]) + fabs(e2[2])) * (1.0 + 0x1p-20));
+    q.pad = 0.0f;
+    const bool ok = lmax < __builtin_inf() && lmin >= 0x1p-16 * absmax && lmin >= 0x1p-12 * lmax;     // (false for NaN)
+    if (!ok) q.a1 = __builtin_inff();
+    out[i] = q;
+}
+
+hipError_t device_build_pre(const DTri* fast_tris, int n, double absmax, DTriPre* out, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_build_pre, dim3((n + 255) / 256), dim3(256), 0, st, fast_tris, n, absmax, out);
+    return hipGetLastError();
+}
+
 hipError_t device_gather_tris(const DTri* tris, const int32_t* d_slots, int n, DTri* out, hipStream_t st)
 {
     if (n > 0) hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), dim3(256), 0, st, tris, d_slots, n, out);

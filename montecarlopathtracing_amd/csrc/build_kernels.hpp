@@ -32,5 +32,7 @@ hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], c
                              int* n_nodes, int* levels, int* n_top, std::vector<double>* top_boxes, double* absmax, hipStream_t st);
 hipError_t device_offset_children(CwNode* nodes, int n, int off, hipStream_t st);     // child >= 0 -> child + off
 hipError_t device_gather_tris(const DTri* tris, const int32_t* d_slots, int n, DTri* out, hipStream_t st);
+// the pre-test's fp32 record of every slot of the fast triangle array (absmax = largest |coordinate| of the scene)
+hipError_t device_build_pre(const DTri* fast_tris, int n, double absmax, DTriPre* out, hipStream_t st);
 
 }  // namespace mcpt

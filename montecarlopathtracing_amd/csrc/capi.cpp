@@ -99,7 +99,7 @@ struct mcpt_device {
     // scene arrays
     DNode* nodes = nullptr; DTri* tris = nullptr; DTriShade* shade = nullptr; DMaterial* materials = nullptr;
     DLight* lights = nullptr; DLightTri* light_tris = nullptr; double* light_cdf = nullptr; uint8_t* texels = nullptr;
-    FastNode* fast_nodes = nullptr; DTri* fast_tris = nullptr; CwNode* cw_nodes = nullptr;
+    FastNode* fast_nodes = nullptr; DTri* fast_tris = nullptr; CwNode* cw_nodes = nullptr; DTriPre* fast_pre = nullptr;
     int trace_mode = MCPT_TRACE_FAST;
     int32_t* d_order = nullptr;            // leaf -> .obj face (device build keeps it for read-back)
     mcpt_bvh_info bi{};
@@ -459,7 +459,7 @@ void mcpt_device_free(mcpt_device* d)
     if (!d) return;
     (void)hipSetDevice(d->ordinal);
     (void)hipDeviceSynchronize();          // frames of a sequence may still be in flight on the caller's streams
-    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->cw_nodes, d->d_order,
+    void* ptrs[] = {d->nodes, d->tris, d->shade, d->materials, d->lights, d->light_tris, d->light_cdf, d->texels, d->fast_nodes, d->fast_tris, d->fast_pre, d->cw_nodes, d->d_order,
                     d->dirs, d->pixels};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& f : d->slot) {
@@ -683,6 +683,16 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         (void)hipFree(d_slots);
         if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("fast triangle gather: ") + hipGetErrorString(e));
     }
+    {
+        // fp32 records of the triangle phase's pre-test, one per slot of the fast triangle array
+        const int n_slots = fast_on_device ? t : int(fb_ro.leaf_tris.size());
+        // (four records of padding: the pre-test reads its triangles in rounds of up to four slots, used or not)
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d->fast_pre), (size_t(n_slots) + 4) * sizeof(DTriPre));
+        if (e == hipSuccess) e = hipMemsetAsync(d->fast_pre + n_slots, 0, 4 * sizeof(DTriPre), d->stream);
+        if (e == hipSuccess) e = device_build_pre(d->fast_tris, n_slots, fb_ro.scene_absmax, d->fast_pre, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("pre-test records: ") + hipGetErrorString(e));
+    }
     lap("culling hierarchy in HBM");
     if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
     for (auto& f : d->slot) {
@@ -710,7 +720,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     S.t = t; S.Lv = bi.Lv; S.Level = bi.Level; S.Nr = bi.Nr;
     S.num_lights = int32_t(s.lights.size()); S.num_materials = int32_t(s.materials.size());
     S.area0 = s.area0;
-    S.fast.cw = d->cw_nodes; S.fast.nodes = nullptr; S.fast.tris = d->fast_tris; S.fast.absmax = fb_ro.scene_absmax;
+    S.fast.cw = d->cw_nodes; S.fast.nodes = nullptr; S.fast.tris = d->fast_tris; S.fast.pre = d->fast_pre; S.fast.absmax = fb_ro.scene_absmax;
     S.fast.enabled = (coords_ok && fb_ro.max_depth < kFastMaxDepth && fb_ro.cw_stack_need < kFastMaxDepth && fb_ro.scene_absmax >= 1e-15 &&
                       fb_ro.scene_absmax <= 1e15) ? 1 : 0;
     // Which shape of the trace engine walks it (wavefront.hip): by default the short-stack one at 4 waves per SIMD -- the hierarchy may
@@ -791,19 +801,23 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
     s->shadow_skipped = c.shadow_skipped;
     s->dom_rays = c.trace_rays; s->dom_node_visits = c.trace_nodes; s->dom_tri_tests = c.trace_tris;
     if (std::getenv("MCPT_PRINT_DIAG")) {
-        const double tot = double(c.pad[5] + c.pad[6] + c.pad[7]);
-        std::fprintf(stderr, "trace diag: inner iters %llu lanes %.1f/64 | tri iters %llu lanes %.1f/64 | idle lanes/iter %.1f | wave time: refill %.1f%% inner %.1f%% tri %.1f%% | cycles/inner iter %.0f cycles/tri iter %.0f\n",
-                     c.pad[0], c.pad[0] ? double(c.pad[1]) / c.pad[0] : 0.0, c.pad[2], c.pad[2] ? double(c.pad[3]) / c.pad[2] : 0.0,
-                     (c.pad[0] + c.pad[2]) ? double(c.pad[4]) / (c.pad[0] + c.pad[2]) : 0.0,
-                     tot ? 100.0 * c.pad[5] / tot : 0.0, tot ? 100.0 * c.pad[6] / tot : 0.0, tot ? 100.0 * c.pad[7] / tot : 0.0,
-                     c.pad[0] ? double(c.pad[6]) / c.pad[0] : 0.0, c.pad[2] ? double(c.pad[7]) / c.pad[2] : 0.0);
+        const double tot = double(c.pad[8] + c.pad[9] + c.pad[10] + c.pad[11]);
+        const double iters = double(c.pad[0] + c.pad[2] + c.pad[4]);
+        auto per = [](unsigned long long a, unsigned long long b) { return b ? double(a) / double(b) : 0.0; };
+        std::fprintf(stderr, "trace diag: inner iters %llu lanes %.1f/64 | pre-test iters %llu lanes %.1f/64 | exact iters %llu lanes %.1f/64 | idle lanes/iter %.1f | "
+                             "wave time: refill %.1f%% inner %.1f%% pre-test %.1f%% exact %.1f%% | cycles per iter: inner %.0f pre-test %.0f exact %.0f\n",
+                     c.pad[0], per(c.pad[1], c.pad[0]), c.pad[2], per(c.pad[3], c.pad[2]), c.pad[4], per(c.pad[5], c.pad[4]), iters ? double(c.pad[6]) / iters : 0.0,
+                     tot ? 100.0 * c.pad[8] / tot : 0.0, tot ? 100.0 * c.pad[9] / tot : 0.0, tot ? 100.0 * c.pad[10] / tot : 0.0, tot ? 100.0 * c.pad[11] / tot : 0.0,
+                     per(c.pad[9], c.pad[0]), per(c.pad[10], c.pad[2]), per(c.pad[11], c.pad[4]));
+        std::fprintf(stderr, "k_wf_trace: %llu rays, %.3f nodes, %.3f triangles visited, %.3f exact tests per ray (%.1f %% of the visited triangles survive the pre-test)\n",
+                     c.trace_rays, per(c.trace_nodes, c.trace_rays), per(c.trace_tris, c.trace_rays), per(c.trace_exact, c.trace_rays), 100.0 * per(c.trace_exact, c.trace_tris));
         std::fprintf(stderr, "rays deferred to the exact walk by k_wf_trace: %llu of %llu\n", c.pad[12], c.trace_rays);
         if (c.pad[13]) std::fprintf(stderr, "finish diag: longest wave %llu steps, %.0f us alive, %.0f us of it in the ray walks (100 MHz ticks; maxima over waves and launches)\n",
                                     c.pad[13], double(c.pad[14]) / 100.0, double(c.pad[15]) / 100.0);
-        const double lt = double(c.pad[8] + c.pad[9] + c.pad[10]);
+        const double lt = double(c.pad[16] + c.pad[17] + c.pad[18]);
         std::fprintf(stderr, "logic diag: resolve %.1f%% compaction %.1f%% shade %.1f%% | cycles per wave: %.0f / %.0f / %.0f (waves %llu)\n",
-                     lt ? 100.0 * c.pad[8] / lt : 0.0, lt ? 100.0 * c.pad[9] / lt : 0.0, lt ? 100.0 * c.pad[10] / lt : 0.0,
-                     c.pad[11] ? double(c.pad[8]) / c.pad[11] : 0.0, c.pad[11] ? double(c.pad[9]) / c.pad[11] : 0.0, c.pad[11] ? double(c.pad[10]) / c.pad[11] : 0.0, c.pad[11]);
+                     lt ? 100.0 * c.pad[16] / lt : 0.0, lt ? 100.0 * c.pad[17] / lt : 0.0, lt ? 100.0 * c.pad[18] / lt : 0.0,
+                     c.pad[19] ? double(c.pad[16]) / c.pad[19] : 0.0, c.pad[19] ? double(c.pad[17]) / c.pad[19] : 0.0, c.pad[19] ? double(c.pad[18]) / c.pad[19] : 0.0, c.pad[19]);
     }
 }
 

@@ -124,10 +124,12 @@ __device__ __forceinline__ V3 barycentric(V3 v1, V3 v2, V3 v3, V3 p)
 
 struct Hit { int leaf; double t; V3 p; };
 struct Work {
-    uint32_t nodes, tris;
+    uint32_t nodes, tris;       // compressed nodes stepped on, triangles visited (persistent engine: put through the pre-test)
     uint32_t rays = 0;          // rays started by the persistent engine
+    uint32_t exact = 0;         // persistent engine: triangles that needed the reference's fp64 test
 #ifdef MCPT_TRACE_DIAG
-    unsigned long long diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // inner iters, inner lanes, tri iters, tri lanes, idle lanes, cycles refill/inner/tri
+    // [0..5] iterations and waiting lanes of the inner / pre-test / exact phase, [6] idle lanes, [8..11] cycles in refill / inner / pre-test / exact
+    unsigned long long diag[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 };
 

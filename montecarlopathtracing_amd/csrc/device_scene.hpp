@@ -56,10 +56,22 @@ struct alignas(64) CwNode {
     uint32_t pad[2];
 };
 
+// fp32 companion of a fast-leaf triangle slot, 48 B = three 16-B loads: what the conservative pre-test of the triangle phase
+// reads (trace_fast.hpp: tri_pre_reject).  v0 = fl32(v1), e1 = fl32(v2 - v1), e2 = fl32(v3 - v1) (differences formed in fp64);
+// a1 >= |e1.x| + |e1.y| + |e1.z|, a2 likewise (rounded up).  a1 = +inf switches the pre-test off for this triangle (an edge so
+// short against the scene's extent, or a sliver so thin, that the error bounds of the test would not cover the reference's own
+// fp64 rounding: build_kernels.hip: k_build_pre).  Only ever used to SKIP the exact test of a triangle that cannot pass it.
+struct alignas(16) DTriPre {
+    float v0[3], a1;
+    float e1[3], a2;
+    float e2[3], pad;
+};
+
 struct DFast {
     const CwNode* cw;          // compressed wide hierarchy (root = 0)
     const FastNode* nodes;
     const DTri* tris;          // DTri records permuted into fast-leaf order (leaf field = reference leaf index)
+    const DTriPre* pre;        // same order: fp32 records of the pre-test
     double absmax;             // largest |coordinate| in the scene
     int32_t enabled;           // 0: scene has coordinates outside [1e-150,1e150] -> reference-shaped walk only
     int32_t stack_limit;       // per-lane stack entries of the trace engine that walks it: picks the short-stack or the deep-stack kernels
@@ -112,7 +124,9 @@ struct DCounters {
     unsigned long long rays_primary, rays_shadow, rays_bounce, node_visits, tri_tests, shade_calls, samples, max_depth;
     unsigned long long shadow_skipped;   // shadow rays the reference traces although their result is never used (light behind the surface)
     unsigned long long trace_rays, trace_nodes, trace_tris;   // work done inside the dominant kernel (k_wf_trace) only
-    unsigned long long pad[16];   // diagnostics (MCPT_TRACE_DIAG builds; [12] = rays k_wf_trace handed to the exact walk)
+    unsigned long long trace_exact;                           // ... triangles of those that survived the pre-test (exact fp64 tests)
+    unsigned long long pad[24];   // diagnostics: [0..11] trace engine (MCPT_TRACE_DIAG builds), [12] rays k_wf_trace handed to the exact walk,
+                                  // [13..15] finishing kernel, [16..19] logic kernel
 };
 
 }  // namespace mcpt

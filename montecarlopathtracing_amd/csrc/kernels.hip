@@ -78,13 +78,7 @@ __global__ void __launch_bounds__(256, WAVES) k_trace_persistent(DScene S, Src s
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
     LaneStats ls;
     Work w = {0, 0};
-#if MCPT_POP_CULL
-    __shared__ unsigned short lds_keys[STACK * 256];
-    unsigned short* keys = lds_keys + threadIdx.x;
-#else
-    unsigned short* keys = nullptr;
-#endif
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
     ls.nodes = w.nodes; ls.tris = w.tris;
     flush_stats(ctr, ls);
 }

@@ -7,15 +7,23 @@
 //     the waves run dry within one small chunk of each other (with 2048-slot chunks to the end, the last waves of a
 //     6-ms launch worked alone for most of a millisecond: 2.5 % of the frame).  Lanes that finish a ray
 //     take the next slots of the range: the refill is a ballot + prefix count, no memory traffic.
-//   * Each lane is a small state machine: IDLE, INNER (about to test the two children of an inner node),
-//     TRI (walking the triangles of a leaf).  Per wave iteration the wave executes ONE phase -- the one most lanes are
-//     waiting for (vote over __ballot masks, slightly biased to the cheaper inner step) -- so a phase always runs with at least a third of the lanes
-//     that have work, instead of every phase running for whoever happens to need it.
+//   * Each lane is a small state machine: IDLE, INNER (about to test the four children of a compressed node), TRI (about to
+//     put the triangles of a leaf through the conservative fp32 pre-test), EXACT (holding triangles that survived it and need
+//     the reference's own fp64 test).  Per wave iteration the wave executes ONE phase -- the one most lanes are waiting for
+//     (vote over __ballot masks, weighted a little toward the cheaper phases) -- so a phase always runs with a good share of
+//     the lanes that have work, instead of every phase running for whoever happens to need it.  Round 2 had two phases and
+//     ran the ~160-instruction fp64 test on every visited triangle (four in five fail it) at 28-36 of 64 lanes; now a leaf
+//     visit is one pre-test pass over its <= 4 triangles (~55 fp32 instructions each, 48-byte records) and only the
+//     survivors queue for the exact test.
 //   * Per-lane traversal stack in LDS ([depth][lane], conflict free); rays that need the reference-shaped walk
 //     (a zero / denormal / non-finite component) are not walked here: their slot goes to a side list that a second,
 //     tiny launch handles, so one such ray cannot hold 63 lanes for the length of an exhaustive walk.
-// Results are bit-identical to trace_closest_fast() and therefore to the reference (same tests, same order of
-// evaluation per candidate, (t, k) lexicographic minimum).
+// Results are bit-identical to trace_closest_fast() and therefore to the reference (same exact tests on every triangle that
+// can pass them, (t, k) lexicographic minimum).
+//
+// Variants that were built, verified bit-exact, measured slower and removed from this file (they are in the
+// history): pair redistribution in the triangle phase, pop-time culling with 16-bit keys, ray supply a batch ahead in registers,
+// near-tie modes 0-2, own-box test and division per passing triangle.
 #pragma once
 #include "trace_fast.hpp"
 #include "wavefront.hpp"
@@ -28,162 +36,113 @@ namespace mcpt {
 #ifndef MCPT_TAIL_CHUNK
 #define MCPT_TAIL_CHUNK 256         /* slots per claim in the last eighth of a launch */
 #endif
-#ifndef MCPT_TRI_BIAS_NUM
-#define MCPT_TRI_BIAS_NUM 3         /* the triangle phase runs when NUM * (lanes waiting for it) > DEN * (lanes waiting for an */
-#endif                              /* inner step).  Sweep NUM/4 (ms per frame): 1: 113.2, 2: 110.1, 3: 108.7, 4 (plain majority): */
-                                    /* 110.5, 5: 111.4, 6: 112.2, 8: 115.1 -- the cheaper phase may run with a few lanes less */
-#ifndef MCPT_TRI_BIAS_DEN
-#define MCPT_TRI_BIAS_DEN 4
+// Phase vote: the phase with the largest weight x (lanes waiting for it) runs.
+#ifndef MCPT_W_INNER
+#define MCPT_W_INNER 4
 #endif
-#ifndef MCPT_INNER_BURST
-#define MCPT_INNER_BURST 1          /* inner-node steps per scheduling vote */
+#ifndef MCPT_W_TRI
+#define MCPT_W_TRI 3
 #endif
-#ifndef MCPT_SLIM_STATE
-#define MCPT_SLIM_STATE 1           /* 1: a register diet for a fourth wave per SIMD -- the next 64 slots are fetched when the LDS batch runs
-                                       out (not a batch ahead, in registers), and of 1/d only the x component is kept (the other two are
-                                       recomputed where a ray is finished) */
+#ifndef MCPT_W_EXACT
+#define MCPT_W_EXACT 3
 #endif
-#ifndef MCPT_TRI_SHARE
-#define MCPT_TRI_SHARE 0            /* 1: the triangle phase hands the pending (ray, triangle) pairs of all its lanes out to all 64 lanes
-                                       (a lane with a 4-triangle leaf gets three helpers) instead of every lane walking its own leaf one
-                                       triangle per iteration at ~28 of 64 lanes.  Measured, not kept: triangle iterations 79.5 M -> 51.0 M
-                                       per frame (all iterations -16 %), but the ~45 cross-lane moves per iteration and 24 spilled
-                                       registers make one such iteration 1.75x as long: 7.75 instead of 6.27 ms per launch. */
+#ifndef MCPT_LEAF_CLASS
+#define MCPT_LEAF_CLASS 1           /* 1: the vote knows two classes -- lanes at a node, lanes at a leaf; a leaf iteration runs the pre-test
+                                       for the lanes that enter a leaf and then one exact test for every lane that holds a survivor (its own
+                                       fresh ones included).  0: three classes, the exact test as a phase of its own. */
 #endif
-#ifndef MCPT_POP_CULL
-#define MCPT_POP_CULL 0             /* 1: every stack entry carries a lower bound of its entry distance (16 bits: the upper half of the
-                                       fp32 bound, i.e. rounded down); an entry popped after the ray's limit has moved in front of it is
-                                       dropped instead of visited */
+#ifndef MCPT_EXACT_MIN
+#define MCPT_EXACT_MIN 1            /* MCPT_LEAF_CLASS: lanes holding a survivor before a leaf iteration runs its exact block */
 #endif
-#ifndef MCPT_INBAND_INPLACE
-#define MCPT_INBAND_INPLACE 3       /* how two candidates the products cannot rank are told apart: 1 = by the reference's own t_k and leaf index on
-                                       the spot; 2 = the contender is remembered and the two are ranked where the ray is finished (fewer
-                                       registers in the triangle phase; a second contender sends the ray to the exact walk); 3 = by t_k and leaf
-                                       index on the spot without the newcomer's own-box test (the leader's is checked at the end anyway);
-                                       0 = the ray goes to the exact walk.  At 4 waves per SIMD (128 VGPRs) every register in the triangle
-                                       phase counts: mode 1 spills 20 registers, mode 2 27; mode 3 with two spilled registers was 11 % slower
-                                       per launch than mode 0 (whose deferred rays, 0.05 % on cornell-box, cost 0.13 ms per launch), with one
-                                       (after the per-lane rank mask went: v_mbcnt) it is 2.5 % faster: 7.37 vs 7.56 ms */
+#ifndef MCPT_PRE_UNROLL
+#define MCPT_PRE_UNROLL 2
 #endif
-#ifndef MCPT_LAZY_VERIFY
-#define MCPT_LAZY_VERIFY 1          /* 1: a triangle whose test passes only has the RANK of its distance looked at (two multiplies);
-                                       the own-box test and the division of t_k are done once per ray, for the winner, when the
-                                       results of a batch of finished rays are stored (>= MCPT_REFILL_LANES lanes at once).  Done per
-                                       passing triangle they ran for ~7 lanes of 64 and were a third of the kernel's instructions. */
+#ifndef MCPT_PRE_TEST
+#define MCPT_PRE_TEST 1             /* 0: every visited triangle survives the pre-test (A/B runs; same results) */
 #endif
 
 // Src must provide:  long long total() const;
 //                    bool fetch(long long q, Ray& r) const;        // false: slot holds no ray (loads may be speculative)
 //                    void store(long long q, bool hit, const Hit& h) const;
 //
-// Ray supply is double-buffered so that its memory latency never stalls the lanes that are walking:
-//   stage 1: the next 64 slots of the wave's chunk are loaded into registers (one slot per lane, issued early, not waited for);
-//   stage 2: when the LDS batch is used up, stage 1 is written to LDS ([component][lane], 52 B per ray) and the following
-//            64 slots are requested at once; idle lanes take entries of the LDS batch by ballot rank.
+// Ray supply: when the wave's LDS batch is used up, the next 64 slots of its chunk are fetched at once (one slot per lane,
+// branch-free, so nothing waits on a flag) into LDS ([component][lane], 52 B per ray); idle lanes take entries by ballot rank.
 #define MCPT_RAYBUF_DOUBLES 6
-#if MCPT_TRI_SHARE
-#define MCPT_RAYBUF_BYTES (64 * (MCPT_RAYBUF_DOUBLES * 8 + 4 + 4))  /* per wave: 64 rays, their flags, and the owner table of MCPT_TRI_SHARE */
-#else
 #define MCPT_RAYBUF_BYTES (64 * (MCPT_RAYBUF_DOUBLES * 8 + 4))      /* per wave: 64 rays and their flags */
-#endif
 
 template <class Src>
 __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src, TraceQueue* queue, long long* __restrict__ slow_list,
                                                  unsigned int slow_cap, long long chunk, int* __restrict__ stack, int stride,
                                                  double* __restrict__ raybuf /* this wave's MCPT_RAYBUF_BYTES of LDS */, Work& w,
-                                                 unsigned short* __restrict__ kstack = nullptr /* MCPT_POP_CULL: [depth][lane] like stack */,
                                                  int stack_cap = MCPT_FAST_STACK /* entries of `stack` per lane */)
 {
     const DFast& F = S.fast;
     const CwNode* __restrict__ nodes = F.cw;
     const DTri* __restrict__ tris = F.tris;
+    const DTriPre* __restrict__ pre = F.pre;
     const long long total = src.total();
     // ticket k < big_tickets: slots [k * chunk, (k + 1) * chunk); later tickets: MCPT_TAIL_CHUNK slots each
     const long long small = chunk < MCPT_TAIL_CHUNK ? chunk : MCPT_TAIL_CHUNK;
     const long long big_tickets = (total - total / 8) / chunk;
     const int lane = threadIdx.x & 63;
-    int* __restrict__ rayflag = reinterpret_cast<int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
-    int* __restrict__ owner_of = rayflag + 64;      // MCPT_TRI_SHARE: pair slot -> owning lane | (triangle offset << 8)
-    (void)owner_of;
+    // behind the rays: three work counters of the wave (nodes, rays, exact tests), bumped by lane 0 with fire-and-forget LDS adds --
+    // as scalars the compiler kept them in scratch memory, as per-lane registers they cost three VGPRs the walk does not have
+    unsigned int* __restrict__ wctr = reinterpret_cast<unsigned int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
+    if (lane < 3) wctr[lane] = 0u;
 
     // wave-uniform supply state
     long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk
     bool queue_empty = false;                   // no more slots anywhere
-    long long reg_base = 0; int reg_count = 0;  // stage 1: slots [reg_base, reg_base+reg_count) in flight / in registers
-    long long lds_base = 0; int lds_count = 0, lds_taken = 0;   // stage 2
-#if !MCPT_SLIM_STATE
-    Ray reg_ray; reg_ray.o = mk(0, 0, 0); reg_ray.d = mk(1, 1, 1);
-    bool reg_valid = false;
-#endif
+    long long reg_base = 0; int reg_count = 0;  // the next <= 64 slots to fetch
+    long long lds_base = 0; int lds_count = 0, lds_taken = 0;   // the batch in LDS
+    unsigned long long lds_valid = 0;           // bit e: entry e of the batch holds a ray
 
     // lane state
-    enum { ST_IDLE = 0, ST_INNER = 1, ST_TRI = 2 };
+    enum { ST_IDLE = 0, ST_INNER = 1, ST_TRI = 2, ST_EXACT = 3 };
     int state = ST_IDLE;
     long long slot = -1;
     Ray r; r.o = mk(0, 0, 0); r.d = mk(1, 1, 1);
-#if MCPT_SLIM_STATE
-    double rcp_x = 1;
-#define MCPT_RCP_X rcp_x
-#define MCPT_FULL_RCP() mk(rcp_x, fast_rcp(r.d.y), fast_rcp(r.d.z))
-#else
-    V3 rcp = mk(1, 1, 1);
-#define MCPT_RCP_X rcp.x
-#define MCPT_FULL_RCP() rcp
-#endif
     RayF rf; for (int a = 0; a < 3; a++) { rf.o[a] = 0; rf.r[a] = 1; rf.pad[a] = 0; }
-    float limit_f = 0;
-    double margin = 0, limit = 0;
+    float limit_f = 0;                          // upper bound (rounded up) of leader's product x (1 + 2^-47) + margin
+    float margin_f = 0;                         // the pruning margin of trace_fast.hpp, rounded up (+inf: no pruning by distance)
     bool found = false;
-    Hit best; best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
-#if MCPT_LAZY_VERIFY
-    // best.t holds the product (p.x - o.x) * (1 / d.x) of the leading candidate (within 2^-50 of its t_k), best.leaf its slot in
-    // the fast triangle array; the candidate is verified (own box) and t_k divided out in finish_ray().
-    bool ambiguous = false;             // two candidates closer than the products can tell apart: the ray goes to the exact walk
-#if MCPT_INBAND_INPLACE == 2
-    int alt = -1;                       // a contender within the products' resolution of the leader (slot in the fast triangle array)
-#endif
-    bool solo = false;                  // MCPT_TRI_SHARE: this lane walks the rest of its leaf itself (a near-tie needs the exact comparison)
-    (void)solo;
-#endif
-    int sp = 0, cur = 0, tri_i = 0, tri_end = 0;
+    // The leading candidate: best_leaf = its slot in the fast triangle array, best_t = the product (p.x - o.x) * (1 / d.x) (within
+    // 2^-50 of its t_k), best_px = its hit point's x (what the reference's t_k is divided out of).  The candidate is verified (own
+    // box), t_k divided out and the hit point formed again in finish_ray(): three registers per lane instead of nine through the
+    // whole walk, for ~45 instructions per ray.
+    int best_leaf = -1;
+    double best_t = 0, best_px = 0;
+    bool ambiguous = false;             // the ray goes to the exact one-lane walk (stack overflow, leader's own box fails)
+    int sp = 0;
+    int cur = 0;                        // ST_INNER: the node to step on; ST_TRI / ST_EXACT: first slot of the leaf's triangles
+    int tri_m = 0;                      // ST_TRI: number of triangles of the leaf; ST_EXACT: bit k set = triangle cur + k awaits the exact test
 
     // A finished ray's result goes to memory (called for a batch of idle lanes at a time).
-    auto finish_ray = [&]() {
-#if MCPT_LAZY_VERIFY
+    auto finish_ray = [&]() __attribute__((always_inline)) {
         // The leading candidate was chosen by rank alone.  It is the reference's answer iff its own box passes the reference's
-        // slab test (a candidate that fails it must not have displaced anything) and no other candidate came within the
-        // resolution of the products; otherwise the ray is re-walked exactly (reference-shaped walk, second launch).
-        Hit h; h.leaf = -1; h.t = 0; h.p = best.p;
+        // slab test (a candidate that fails it must not have displaced anything); otherwise the ray is re-walked exactly.
+        Hit h; h.leaf = -1; h.t = 0; h.p = mk(0, 0, 0);
         if (found) {
-            const V3 rc = MCPT_FULL_RCP();
-            const DTri* tr = tris + best.leaf;
+            const V3 rc = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+            const DTri* tr = tris + best_leaf;
             if (!own_box_hit(tr, r, rc)) ambiguous = true;
             h.leaf = tr->leaf;
-            h.t = (best.p.x - r.o.x) / r.d.x;                   // pathTracing.cpp:347
-#if MCPT_INBAND_INPLACE == 2
-            if (alt >= 0 && !ambiguous) {
-                // the contender: its hit point again (the same arithmetic gives the same bits), its own box, then the reference's order
-                const DTri* ta_ = tris + alt;
-                V3 pa;
-                if (tri_hit(ta_, r, pa) && own_box_hit(ta_, r, rc)) {
-                    const double t_alt = (pa.x - r.o.x) / r.d.x;
-                    if (t_alt > 0 && (t_alt < h.t || (t_alt == h.t && ta_->leaf < h.leaf))) { h.leaf = ta_->leaf; h.t = t_alt; h.p = pa; }
-                }
-            }
-#endif
+            h.t = (best_px - r.o.x) / r.d.x;                    // pathTracing.cpp:347
+            // the hit point: the first two lines of intersect(Ray&, Face&, Vertex&) again -- the same operations on the same
+            // operands give the same bits as when the triangle was tested
+            const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
+            const double t = dot(v1 - r.o, n) / dot(n, r.d);
+            h.p = r.o + r.d * t;
         }
         if (ambiguous) {
             const unsigned int at = atomicAdd(&queue->slow_count, 1u);
             if (at < slow_cap) slow_list[at] = slot;
             else queue->redo_all = 1u;                          // list full: the second pass re-walks every slot
         } else src.store(slot, found, h);
-#else
-        src.store(slot, found, best);
-#endif
     };
 
-    // claim the next <= 64 slots and issue their loads (stage 1)
-    auto request = [&]() {
+    // claim the next <= 64 slots
+    auto request = [&]() __attribute__((always_inline)) {
         reg_count = 0;
         if (queue_empty) return;
         if (next >= range_end) {
@@ -200,16 +159,28 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         reg_count = avail < 64 ? (int)avail : 64;
         reg_base = next;
         next += reg_count;
-#if !MCPT_SLIM_STATE
-        reg_valid = lane < reg_count && src.fetch(reg_base + lane, reg_ray);
-#endif
     };
     request();
+
+    // the next entry of this lane's stack becomes its work; nothing left: the ray is finished (its result is stored at the next refill)
+    auto pop_next = [&]() __attribute__((always_inline)) {
+        // (selects, not branches that assign different variables: the compiler merges such stores into one through a computed
+        // address, which pins the variables to scratch memory)
+        if (sp > 0) {
+            sp--;
+            const int nxt = stack[sp * stride];
+            const bool node = nxt >= 0;
+            const int ref = -1 - nxt;
+            cur = node ? nxt : ref >> 4;
+            tri_m = node ? tri_m : (ref & 7) + 1;
+            state = node ? ST_INNER : ST_TRI;
+        } else state = ST_IDLE;
+    };
 
 #ifdef MCPT_TRACE_DIAG
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
     int last_phase = 0;
-#define MCPT_STAMP(ph) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) w.diag[5 + last_phase] += t_now - t_prev; t_prev = t_now; last_phase = ph; }
+#define MCPT_STAMP(ph) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) w.diag[8 + last_phase] += t_now - t_prev; t_prev = t_now; last_phase = ph; }
 #else
 #define MCPT_STAMP(ph)
 #endif
@@ -225,15 +196,13 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
             for (;;) {
                 idle = __ballot(state == ST_IDLE);
                 if (!idle) break;
-                if (lds_taken >= lds_count) {            // stage 1 -> stage 2, and ask for the batch after it
+                if (lds_taken >= lds_count) {            // the next batch into LDS
                     if (reg_count == 0) break;           // nothing left anywhere
-#if MCPT_SLIM_STATE
                     Ray reg_ray; reg_ray.o = mk(0, 0, 0); reg_ray.d = mk(1, 1, 1);
                     const bool reg_valid = lane < reg_count && src.fetch(reg_base + lane, reg_ray);
-#endif
                     raybuf[0 * 64 + lane] = reg_ray.o.x; raybuf[1 * 64 + lane] = reg_ray.o.y; raybuf[2 * 64 + lane] = reg_ray.o.z;
                     raybuf[3 * 64 + lane] = reg_ray.d.x; raybuf[4 * 64 + lane] = reg_ray.d.y; raybuf[5 * 64 + lane] = reg_ray.d.z;
-                    rayflag[lane] = reg_valid ? 1 : 0;
+                    lds_valid = __ballot(reg_valid);
                     lds_base = reg_base; lds_count = reg_count; lds_taken = 0;
                     request();
                 }
@@ -242,35 +211,26 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                 const int give = want < avail ? want : avail;
                 // set bits of `idle` below this lane (v_mbcnt: no per-lane mask register to keep)
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
+                bool started = false;
                 if (state == ST_IDLE && rank < give) {
                     const int e = lds_taken + rank;
-                    if (rayflag[e]) {
+                    if ((lds_valid >> e) & 1ull) {
                         Ray nr;
                         nr.o = mk(raybuf[0 * 64 + e], raybuf[1 * 64 + e], raybuf[2 * 64 + e]);
                         nr.d = mk(raybuf[3 * 64 + e], raybuf[4 * 64 + e], raybuf[5 * 64 + e]);
                         const long long q = lds_base + e;
                         if (fast_path_ok(F, nr)) {
-                            w.rays++;
                             slot = q; r = nr;
-#if MCPT_SLIM_STATE
                             const V3 rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
-                            rcp_x = rcp.x;
-#else
-                            rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
-#endif
                             const double rmax = fmax(fmax(fabs(rcp.x), fabs(rcp.y)), fabs(rcp.z));     // = 1 / min|d_k|
                             const double scale = fmax(fmax(F.absmax, fabs(r.o.x)), fmax(fabs(r.o.y), fabs(r.o.z)));
-                            margin = rmax <= 1e6 ? 1.0000001e-9 * scale * rmax : __builtin_inf();
-                            limit = __builtin_inf(); limit_f = __builtin_inff();
+                            margin_f = rmax <= 1e6 ? __double2float_ru(1.0000001e-9 * scale * rmax) : __builtin_inff();
+                            limit_f = __builtin_inff();
                             rf = make_rayf(F, r, rcp);
-                            found = false; best.leaf = -1; best.t = 0; best.p = mk(0, 0, 0);
-#if MCPT_LAZY_VERIFY
+                            found = false; best_leaf = -1; best_t = 0; best_px = 0;
                             ambiguous = false;
-#if MCPT_INBAND_INPLACE == 2
-                            alt = -1;
-#endif
-#endif
                             sp = 0; cur = 0; state = ST_INNER;
+                            started = true;
                         } else {
                             const unsigned int at = atomicAdd(&queue->slow_count, 1u);
                             if (at < slow_cap) slow_list[at] = q;    // list full: the second pass scans every slot instead
@@ -278,220 +238,135 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                     }
                 }
                 lds_taken += give;
+                { const unsigned int n_started = (unsigned int)__popcll(__ballot(started)); if (lane == 0 && n_started) atomicAdd(&wctr[1], n_started); }
             }
         }
         // ------------------------------------------------------------------ pick the phase most lanes wait for
-        const unsigned long long m_inner = __ballot(state == ST_INNER);
-        const unsigned long long m_tri = __ballot(state == ST_TRI);
-        if (!m_inner && !m_tri) {
+        const int n_inner = __popcll(__ballot(state == ST_INNER));
+        const int n_tri = __popcll(__ballot(state == ST_TRI));
+        const int n_exact = __popcll(__ballot(state == ST_EXACT));
+        if (!(n_inner | n_tri | n_exact)) {
             if (lds_taken >= lds_count && reg_count == 0) break;      // no walking lane and no ray left to hand out
             continue;
         }
+#if MCPT_LEAF_CLASS
+        // two classes: lanes at a node, lanes at a leaf (pre-test or exact stage); the leaf phase runs both of its blocks
+        const int phase = (MCPT_W_INNER * n_inner >= MCPT_W_TRI * (n_tri + n_exact)) ? ST_INNER : ST_TRI;
+#else
+        const int s_inner = MCPT_W_INNER * n_inner, s_tri = MCPT_W_TRI * n_tri, s_exact = MCPT_W_EXACT * n_exact;
+        const int phase = (s_inner >= s_tri && s_inner >= s_exact) ? ST_INNER : (s_tri >= s_exact ? ST_TRI : ST_EXACT);
+#endif
 #ifdef MCPT_TRACE_DIAG
         if (lane == 0) {
-            const bool in = __popcll(m_inner) >= __popcll(m_tri);
-            w.diag[in ? 0 : 2] += 1; w.diag[in ? 1 : 3] += in ? __popcll(m_inner) : __popcll(m_tri);
-            w.diag[4] += 64 - __popcll(m_inner) - __popcll(m_tri);
+            const int k = phase - 1;                                   // 0 inner, 1 tri, 2 exact
+            w.diag[2 * k] += 1; w.diag[2 * k + 1] += phase == ST_INNER ? n_inner : (phase == ST_TRI ? n_tri : n_exact);
+            w.diag[6] += 64 - n_inner - n_tri - n_exact;
+#if MCPT_LEAF_CLASS
+            if (phase == ST_TRI) { w.diag[4] += 1; w.diag[5] += n_exact; }      // exact-stage lanes at the start of a leaf iteration
+#endif
         }
 #endif
-        const bool run_inner = m_inner && MCPT_TRI_BIAS_DEN * __popcll(m_inner) >= MCPT_TRI_BIAS_NUM * __popcll(m_tri);
-        MCPT_STAMP(run_inner ? 1 : 2)
-        if (run_inner) {
-            // -------------------------------------------------------------- inner steps (a short burst per vote)
-#pragma unroll 1
-            for (int burst = 0; burst < MCPT_INNER_BURST; burst++)
+        MCPT_STAMP(phase)
+        if (phase == ST_INNER) {
+            // -------------------------------------------------------------- one step on a compressed node
+            // three pushes must fit: a ray whose stack would overflow (the hierarchy is built not to need that) goes to the exact walk
+            const bool over = state == ST_INNER && sp > stack_cap - 3;
+            { const unsigned int n_step = (unsigned int)(n_inner - __popcll(__ballot(over))); if (lane == 0) atomicAdd(&wctr[0], n_step); }
             if (state == ST_INNER) {
-#if MCPT_LAZY_VERIFY
-                // three pushes must fit: a ray whose stack would overflow (the hierarchy is built not to need that) goes to the exact walk
-                if (sp > stack_cap - 3) { ambiguous = true; state = ST_IDLE; }
+                if (over) { ambiguous = true; state = ST_IDLE; }
                 else {
+                    const CwHits h = cw_step(nodes + cur, rf, limit_f);
+                    // nearest first; the others go on the stack so that the next nearest is on top
+                    if (h.ref[3] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[3]; sp++; }
+                    if (h.ref[2] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[2]; sp++; }
+                    if (h.ref[1] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[1]; sp++; }
+                    int nxt = h.ref[0];
+                    if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = stack[sp * stride]; }
+                    const bool node = nxt >= 0, none = nxt == MCPT_FAST_EMPTY;
+                    const int ref = -1 - nxt;
+                    cur = node ? nxt : ref >> 4;
+                    tri_m = node ? tri_m : (ref & 7) + 1;
+                    state = node ? ST_INNER : (none ? ST_IDLE : ST_TRI);     // (ST_IDLE: the result is stored at the next refill)
+                }
+            }
+        }
+#if MCPT_LEAF_CLASS
+        if (phase == ST_TRI && n_tri) {
 #else
-                {
+        else if (phase == ST_TRI) {
 #endif
-                w.nodes++;
-                const CwHits h = cw_step(nodes + cur, rf, limit_f);
-                // nearest first; the others go on the stack so that the next nearest is on top
-#if MCPT_POP_CULL
-#define MCPT_KEY16(x) ((unsigned short)(__float_as_uint(fmaxf((x), 0.0f)) >> 16))
-                if (h.ref[3] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[3]; kstack[sp * stride] = MCPT_KEY16(h.key[3]); sp++; }
-                if (h.ref[2] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[2]; kstack[sp * stride] = MCPT_KEY16(h.key[2]); sp++; }
-                if (h.ref[1] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[1]; kstack[sp * stride] = MCPT_KEY16(h.key[1]); sp++; }
-                int nxt = h.ref[0];
-                if (nxt == MCPT_FAST_EMPTY) {
-                    while (sp > 0) {
-                        sp--;
-                        if (__uint_as_float((unsigned)kstack[sp * stride] << 16) <= limit_f) { nxt = stack[sp * stride]; break; }
+            // -------------------------------------------------------------- the triangles of a leaf through the fp32 pre-test
+            if (state == ST_TRI) {
+                unsigned int surv = 0;
+#if MCPT_PRE_TEST
+                const PreRay pr = make_pre_ray(F, r, rf.o, margin_f);
+                w.tris += tri_m;
+                // MCPT_PRE_UNROLL triangles per round: their records are requested together, so a round costs one memory latency
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (int k0 = 0; k0 < tri_m; k0 += MCPT_PRE_UNROLL) {
+#pragma unroll
+                    for (int j = 0; j < MCPT_PRE_UNROLL; j++) {
+                        const int k = k0 + j;
+                        // (a slot past the leaf's last is a triangle of the next leaf or the array's padding: tested, not used)
+                        const bool rej = tri_pre_reject(pre + cur + k, pr, limit_f);
+                        if (k < tri_m && !rej) surv |= 1u << k;
                     }
                 }
 #else
-                if (h.ref[3] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[3]; sp++; }
-                if (h.ref[2] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[2]; sp++; }
-                if (h.ref[1] != MCPT_FAST_EMPTY) { stack[sp * stride] = h.ref[1]; sp++; }
-                int nxt = h.ref[0];
-                if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = stack[sp * stride]; }
+                w.tris += tri_m;
+                surv = (1u << tri_m) - 1u;
 #endif
-                if (nxt >= 0) cur = nxt;
-                else if (nxt == MCPT_FAST_EMPTY) state = ST_IDLE;                 // result stored at the next refill
-                else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; state = ST_TRI; }
-                }
+                if (surv) { tri_m = (int)surv; state = ST_EXACT; }
+                else pop_next();
             }
-        } else {
-            // -------------------------------------------------------------- triangles of the current leaves
-            // one triangle of this lane's own leaf, the sequential way
-            auto test_own_triangle = [&]() {
-                const DTri* tr = tris + tri_i;
-                tri_i++;
+        }
+#if MCPT_LEAF_CLASS
+        // the exact block runs once enough lanes hold a survivor (or nothing else is waiting at a leaf): below that they wait, as
+        // members of the leaf class, for the next leaf iteration
+        const int n_hold = phase == ST_TRI ? __popcll(__ballot(state == ST_EXACT)) : 0;
+        if (n_hold >= MCPT_EXACT_MIN || (n_hold && (!n_tri || n_hold >= n_tri + n_exact))) {
+            if (lane == 0) atomicAdd(&wctr[2], (unsigned int)n_hold);
+#else
+        else if (phase == ST_EXACT) {
+            if (lane == 0) atomicAdd(&wctr[2], (unsigned int)n_exact);
+#endif
+            // -------------------------------------------------------------- one surviving triangle through the reference's test
+            if (state == ST_EXACT) {
+                const int k = __ffs(tri_m) - 1;
+                tri_m &= tri_m - 1;
+                const int ti = cur + k;
+                const DTri* tr = tris + ti;
                 // Candidate = own box passes AND triangle test passes AND t > 0 -- a conjunction of pure tests, so the
-                // order of evaluation is free: the triangle test goes first (about one visited triangle in five passes it),
-                // the rest (better_candidate) is evaluated only for those.
+                // order of evaluation is free: the triangle test goes first, the own box is looked at once per ray (finish_ray).
                 V3 p;
-                w.tris++;
                 if (tri_hit(tr, r, p)) {
-#if MCPT_LAZY_VERIFY
                     // t_k = (p.x - o.x) / d.x is within 2^-50 (relative) of this product and has its sign: two candidates whose
                     // products differ by more than 2^-47 are ranked like their t_k
-                    const double ta = (p.x - r.o.x) * MCPT_RCP_X;
+                    const double ta = (p.x - r.o.x) * fast_rcp(r.d.x);
                     if (ta > 0.0) {
-                        const double band = best.t * 0x1p-47;
-                        if (!found || ta < best.t - band) {
-#if MCPT_INBAND_INPLACE == 2
-                            // a remembered contender lies within one band of the old leader: it stays clearly behind the new leader
-                            // only if that one leads by more than four bands
-                            if (found && alt >= 0) { if (ta < best.t - 4.0 * band) alt = -1; else ambiguous = true; }
-#endif
-                            found = true; best.leaf = tri_i - 1; best.t = ta; best.p = p;
-                            limit = (ta + ta * 0x1p-47) + margin;
-                            limit_f = __double2float_ru(limit);
-                        } else if (!(ta > best.t + band)) {
+                        const double band = best_t * 0x1p-47;
+                        if (!found || ta < best_t - band) {
+                            found = true; best_leaf = ti; best_t = ta; best_px = p.x;
+                            limit_f = __double2float_ru((ta + ta * 0x1p-47) + (double)margin_f);
+                        } else if (!(ta > best_t + band)) {
                             // closer to the leader than the products resolve (a shared edge, a face listed twice, two sides of
-                            // a sheet): rank the two by the reference's own t_k and leaf index, provided this one is a candidate
-                            // at all.  The leader's own box is looked at when the ray is finished, like any leader's.
-#if !MCPT_INBAND_INPLACE
-                            ambiguous = true;
-#elif MCPT_INBAND_INPLACE == 3
-                            // the reference's own order of the two, (t_k, k): whether either is a candidate at all (its own box) is not
-                            // looked at here -- a non-candidate that takes or keeps the lead here can only be displaced by something
-                            // closer still, and if it is still leading when the ray is finished the own-box test there sends the ray
-                            // to the exact walk
-                            {
-                                const double t_new = (p.x - r.o.x) / r.d.x, t_old = (best.p.x - r.o.x) / r.d.x;
-                                if (t_new < t_old || (t_new == t_old && tr->leaf < tris[best.leaf].leaf)) {
-                                    best.leaf = tri_i - 1; best.t = ta; best.p = p;
-                                }
+                            // a sheet): the reference's own order of the two, (t_k, k).  Whether either is a candidate at all (its
+                            // own box) is not looked at here -- a non-candidate that takes or keeps the lead here can only be
+                            // displaced by something closer still, and if it is still leading when the ray is finished the own-box
+                            // test there sends the ray to the exact walk
+                            const double t_new = (p.x - r.o.x) / r.d.x, t_old = (best_px - r.o.x) / r.d.x;
+                            if (t_new < t_old || (t_new == t_old && tr->leaf < tris[best_leaf].leaf)) {
+                                best_leaf = ti; best_t = ta; best_px = p.x;
                             }
-#elif MCPT_INBAND_INPLACE == 2
-                            if (alt < 0) alt = tri_i - 1; else ambiguous = true;
-#else
-                            if (own_box_hit(tr, r, MCPT_FULL_RCP())) {
-                                const double t_new = (p.x - r.o.x) / r.d.x, t_old = (best.p.x - r.o.x) / r.d.x;
-                                if (t_new < t_old || (t_new == t_old && tr->leaf < tris[best.leaf].leaf)) {
-                                    best.leaf = tri_i - 1; best.t = ta; best.p = p;
-                                }
-                            }
-#endif
                         }
                     }
-#else
-                    double t; int k;
-                    if (better_candidate(tr, r, rcp, p, found, best, t, k)) {
-                        found = true; best.leaf = k; best.t = t; best.p = p;
-                        limit = t + margin;
-                        limit_f = __double2float_ru(limit);
-                    }
-#endif
                 }
-            };
-#if MCPT_TRI_SHARE && MCPT_LAZY_VERIFY
-            {
-                // pending pairs of this wave: lane L owns c(L) <= 4 of them; pair g = excl(L) + j is tested by lane g (g < 64)
-                int c = (state == ST_TRI && !solo) ? tri_end - tri_i : 0;
-                c = c > 4 ? 4 : c;
-                int incl = c;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-                const int excl = incl - c;
-                const int total = __shfl(incl, 63, 64);
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (k < c && excl + k < 64) owner_of[excl + k] = lane | (k << 8);
-                const bool work = lane < total;
-                int ow = lane, kk = 0;
-                if (work) { const int e = owner_of[lane]; ow = e & 255; kk = e >> 8; }
-                // the owner's ray, as far as the test and the rank of the distance need it
-                Ray hr;
-                hr.o = mk(__shfl(r.o.x, ow, 64), __shfl(r.o.y, ow, 64), __shfl(r.o.z, ow, 64));
-                hr.d = mk(__shfl(r.d.x, ow, 64), __shfl(r.d.y, ow, 64), __shfl(r.d.z, ow, 64));
-                const double h_rcpx = __shfl(MCPT_RCP_X, ow, 64), h_best = __shfl(best.t, ow, 64);
-                const int h_found = __shfl((int)found, ow, 64);
-                const int h_tri = __shfl(tri_i, ow, 64) + kk;
-                V3 hp = mk(0, 0, 0);
-                double h_ta = __builtin_inf();          // +inf: no candidate from this pair
-                if (work) {
-                    w.tris++;
-                    if (tri_hit(tris + h_tri, hr, hp)) {
-                        const double ta = (hp.x - hr.o.x) * h_rcpx;
-                        // certainly farther than the owner's leader: not a candidate (same rule as the sequential code)
-                        if (ta > 0.0 && !(h_found && ta > h_best + h_best * 0x1p-47)) h_ta = ta;
-                    }
-                }
-                // owners collect: the smallest product among their pairs, and whether anything comes within the products' resolution
-                // of it (another pair, or the current leader) -- then the lane walks this leaf itself, with the exact comparison
-                const int done = c < 64 - excl ? c : (64 - excl > 0 ? 64 - excl : 0);      // pairs of this lane that were tested
-                double m1 = __builtin_inf(), m2 = __builtin_inf();
-                int src = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int from = (excl + k) & 63;
-                    const double tk = __shfl(h_ta, from, 64);
-                    if (k < done) {
-                        if (tk < m1) { m2 = m1; m1 = tk; src = from; }
-                        else if (tk < m2) m2 = tk;
-                    }
-                }
-                const V3 wp = mk(__shfl(hp.x, src, 64), __shfl(hp.y, src, 64), __shfl(hp.z, src, 64));
-                if (done > 0) {
-                    const bool any = m1 < __builtin_inf();
-                    const bool near_other = m2 <= m1 + m1 * 0x1p-46;                              // (inf <= inf: only when any)
-                    const bool near_leader = found && !(m1 < best.t - best.t * 0x1p-47);           // a candidate is never certainly farther
-                    if (any && (near_other || near_leader)) solo = true;                          // nothing taken, nothing skipped
-                    else {
-                        if (any) {
-                            found = true; best.leaf = tri_i + ((src - excl) & 63); best.t = m1; best.p = wp;
-                            limit = (m1 + m1 * 0x1p-47) + margin;
-                            limit_f = __double2float_ru(limit);
-                        }
-                        tri_i += done;
-                    }
-                }
-                if (__ballot(state == ST_TRI && solo)) { if (state == ST_TRI && solo) test_own_triangle(); }
-            }
-#else
-            if (state == ST_TRI) test_own_triangle();
-#endif
-            if (state == ST_TRI && tri_i >= tri_end) {   // leaf done: pop
-#if MCPT_LAZY_VERIFY
-                solo = false;
-#endif
-#if MCPT_POP_CULL
-                int nxt = MCPT_FAST_EMPTY;
-                while (sp > 0) {
-                    sp--;
-                    if (__uint_as_float((unsigned)kstack[sp * stride] << 16) <= limit_f) { nxt = stack[sp * stride]; break; }
-                }
-                if (nxt >= 0) { cur = nxt; state = ST_INNER; }
-                else if (nxt == MCPT_FAST_EMPTY) state = ST_IDLE;
-                else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
-#else
-                if (sp > 0) {
-                    sp--;
-                    const int nxt = stack[sp * stride];
-                    if (nxt >= 0) { cur = nxt; state = ST_INNER; }
-                    else { const int ref = -1 - nxt; tri_i = ref >> 4; tri_end = tri_i + (ref & 7) + 1; }
-                } else state = ST_IDLE;
-#endif
+                if (!tri_m) pop_next();
             }
         }
     }
     if (slot >= 0) finish_ray();
+    if (lane == 0) { w.nodes += wctr[0]; w.rays += wctr[1]; w.exact += wctr[2]; }     // (summed over the wave by the caller)
 }
 
 // second pass: the deferred rays, one lane each, reference-shaped walk.  If more rays were deferred than the side list

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         MCPT_LSTAMP(2)
     }
 #ifdef MCPT_TRACE_DIAG
-    if ((threadIdx.x & 63) == 0 && a.ctr) { for (int k = 0; k < 3; k++) atomicAdd(&a.ctr->pad[8 + k], dg[k]); atomicAdd(&a.ctr->pad[11], 1ull); }
+    if ((threadIdx.x & 63) == 0 && a.ctr) { for (int k = 0; k < 3; k++) atomicAdd(&a.ctr->pad[16 + k], dg[k]); atomicAdd(&a.ctr->pad[19], 1ull); }
 #endif
     flush_stats(a.ctr, ls);
 }
@@ -295,23 +295,19 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_trace(DScene S, WfArgs a, Tra
     const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk, max_chunk);
     __shared__ int lds_stack[STACK * 256];
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
-#if MCPT_POP_CULL
-    __shared__ unsigned short lds_keys[STACK * 256];
-    unsigned short* keys = lds_keys + threadIdx.x;
-#else
-    unsigned short* keys = nullptr;
-#endif
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
-    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, keys, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
+    trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
     ls.nodes = w.nodes; ls.tris = w.tris;
     if (a.ctr) {        // the dominant kernel's own work, for its roofline
-        const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays);
-        if ((threadIdx.x & 63) == 0 && tr) { atomicAdd(&a.ctr->trace_nodes, tn); atomicAdd(&a.ctr->trace_tris, tt); atomicAdd(&a.ctr->trace_rays, tr); }
+        const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays), te = wave_sum(w.exact);
+        if ((threadIdx.x & 63) == 0 && tr) {
+            atomicAdd(&a.ctr->trace_nodes, tn); atomicAdd(&a.ctr->trace_tris, tt); atomicAdd(&a.ctr->trace_rays, tr); atomicAdd(&a.ctr->trace_exact, te);
+        }
     }
 #ifdef MCPT_TRACE_DIAG
-    if ((threadIdx.x & 63) == 0 && a.ctr) for (int i = 0; i < 8; i++) atomicAdd(&a.ctr->pad[i], w.diag[i]);
+    if ((threadIdx.x & 63) == 0 && a.ctr) for (int i = 0; i < 12; i++) atomicAdd(&a.ctr->pad[i], w.diag[i]);
 #endif
     flush_stats(a.ctr, ls);
 }

@@ -11,7 +11,7 @@ base="-O3 -std=c++17 -fPIC -ffp-contract=off -pthread -Wall -Wno-unused-function
 for f in kernels wavefront build_kernels; do
   $HIPCC $base --offload-arch=gfx950 -c -o variants/obj_$name/$f.o $f.hip &
 done
-for f in capi scene_loader bvh_build accel_build png_writer output_formats jpeg_decoder multi_device; do
+for f in capi scene_loader bvh_build accel_build png_writer output_formats jpeg_decoder multi_device build_id; do
   [ -f $f.cpp ] && g++ $base -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c -o variants/obj_$name/$f.o $f.cpp &
 done
 wait

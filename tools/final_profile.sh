@@ -14,12 +14,12 @@ timeout -k 10 300 python3 bench.py > $out/bench.json 2> $out/bench.err
 cut -c1-300 $out/bench.json
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats -o p --output-format csv -- python3 $root/bench.py --no-cpu-baseline > $out/stats.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace -d $out/kt8 -o kt --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --sim-world 8 --no-pipeline > $out/kt8.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace -d $out/kt8 -o kt --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --sim-world 8 > $out/kt8.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c -d $out/pmc/$c -o pmc --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > $out/pmc_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c -d $out/pmc/$c -o pmc --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$c.log 2>&1
 done
 cd $root
-python3 tools/pmc_to_traffic.py $out/pmc k_wf_trace "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline (cornell-box 1280x720 SPP 256)" $out/hbm_traffic.json > /dev/null
+python3 tools/pmc_to_traffic.py $out/pmc k_wf_trace "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (cornell-box 1280x720 SPP 256)" $out/hbm_traffic.json > /dev/null
 python3 tools/pmc_summary.py $out/pmc k_wf > $out/pmc_hbm_traffic.txt
 bash tools/pmc_trace.sh gpurun_out/$tag/pmc_sq > $out/pmc_sq.log 2>&1
 python3 tools/pmc_issue.py $out/pmc_sq k_wf_trace $out/issue_utilisation.json "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (cornell-box 1280x720 SPP 256)"
@@ -31,5 +31,5 @@ done
 timeout -k 10 200 python3 bench.py --scene veach-mis --spp 100 --steps 5 --no-cpu-baseline > $out/veach_mis_spp100.json 2>> $out/bench.err
 timeout -k 10 300 python3 bench.py --scene interior --steps 3 --no-cpu-baseline > $out/interior_spp256.json 2>> $out/bench.err
 timeout -k 10 400 python3 bench.py --scene synthetic --spp 16 --steps 3 --no-cpu-baseline > $out/synthetic10m_spp16.json 2>> $out/bench.err
-timeout -k 10 600 python3 bench.py --scene synthetic --width 3840 --height 2160 --spp 1024 --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > $out/synthetic10m_3840x2160_spp1024.json 2>> $out/bench.err
+timeout -k 10 600 python3 bench.py --scene synthetic --width 3840 --height 2160 --spp 1024 --steps 1 --warmup 0 --no-cpu-baseline > $out/synthetic10m_3840x2160_spp1024.json 2>> $out/bench.err
 for f in veach_mis_spp100 interior_spp256 synthetic10m_spp16 synthetic10m_3840x2160_spp1024; do python3 -c "import json; d=json.load(open('$out/$f.json')); print('$f', round(d['ms_per_step'],2), 'ms', round(d['value'],1), 'Mrays/s', round(d['nodes_per_ray'],1), round(d['tris_per_ray'],1))"; done

@@ -14,7 +14,7 @@ sets=(
 i=0
 for s in "${sets[@]}"; do
   cd /tmp
-  timeout -k 10 300 rocprofv3 --pmc $s -d "$root/$out/set$i" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > "$root/$out/set$i.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $s -d "$root/$out/set$i" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$root/$out/set$i.log" 2>&1
   cd "$root"
   i=$((i+1))
 done
