@@ -694,7 +694,7 @@ def test_bench_refuses_more_gpus_than_visible_and_quotes_only_profiles_of_the_lo
 
 def _oracle_pixels_of_full_frame(oracle, prefix, texture_dir, spp, seed, full, name):
     """A BASELINE frame at its own size and SPP against the oracle where the oracle can follow in seconds: a 64x36-pixel crop
-    around the frame's centre and 2 000 pixels drawn at random, every one at the full SPP (a pixel is the float fold of its spp
+    around the frame's centre and 2 000 pixels drawn at random (400 on the interior), every one at the full SPP (a pixel is the float fold of its spp
     samples in order on both sides, so a pixel either agrees to the accumulator's rounding or holds a flipped sample)."""
     osc = oracle.OracleScene(prefix, texture_dir=texture_dir)
     H, W = osc.height, osc.width
@@ -704,12 +704,22 @@ def _oracle_pixels_of_full_frame(oracle, prefix, texture_dir, spp, seed, full, n
     osc.render(spp, seed=seed, rows=(r0, r0 + 36), cols=(c0, c0 + 64), img=ref)
     mask = np.zeros((H, W), dtype=bool)
     mask[r0:r0 + 36, c0:c0 + 64] = True
+    # the scattered pixels: a 1x1 crop is one block of the oracle's OpenMP loop, so the pixels are spread over host threads here (ctypes
+    # drops the GIL, the scene is read-only, every call writes its own pixel of `ref`).  The exhaustive walk of the reference costs
+    # ~170 box tests per ray on cornell-box and thousands on the 204 k-triangle interior: fewer pixels there.
+    import concurrent.futures
     rng = np.random.default_rng(2024)
-    for pix in rng.choice(H * W, size=2000, replace=False):
-        r, c = divmod(int(pix), W)
-        if not mask[r, c]:
-            osc.render(spp, seed=seed, rows=(r, r + 1), cols=(c, c + 1), img=ref)
-            mask[r, c] = True
+    picks = [divmod(int(p), W) for p in rng.choice(H * W, size=2000 if name != "interior" else 400, replace=False)]
+    picks = [(r, c) for r, c in picks if not mask[r, c]]
+    workers = max(1, min(32, (os.cpu_count() or 8) - 1))
+
+    def some(chunk):
+        for r, c in chunk:
+            osc.render(spp, seed=seed, rows=(r, r + 1), cols=(c, c + 1), nthreads=1, img=ref)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+        list(pool.map(some, [picks[i::workers] for i in range(workers)]))
+    for r, c in picks:
+        mask[r, c] = True
     osc.close()
     got, want = full[mask], ref[mask]
     rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-6)
