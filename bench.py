@@ -206,13 +206,12 @@ def run_capi(args):
         nbuf = 2 if args.pipeline else 1
         bufs = [hip_rt.DeviceBuffer(H * W * 24) for _ in range(nbuf)]
         streams = [hip_rt.Stream() for _ in range(nbuf)]
-        flags = (M.RENDER_PIPELINE | M.RENDER_KEEP_STATS) if args.pipeline else 0
+        flags = (M.RENDER_PIPELINE | M.RENDER_KEEP_STATS) if args.pipeline else M.RENDER_KEEP_STATS
         turn = [0]
 
         def frame(stats):
             t = turn[0] = (turn[0] + 1) % nbuf
-            dev.render_device(bufs[t].ptr.value, args.spp, args.seed, rank, world, flags=flags, stats=None if args.pipeline else stats,
-                              stream=streams[t].h.value)
+            dev.render_device(bufs[t].ptr.value, args.spp, args.seed, rank, world, flags=flags, stats=None, stream=streams[t].h.value)
             if not args.pipeline:
                 streams[t].synchronize()
 
@@ -223,19 +222,15 @@ def run_capi(args):
         for _ in range(max(args.warmup, nbuf if args.pipeline else 0)):   # (both frame slots get their workspace outside the timed region)
             frame(M.Stats())
         sync()
-        if args.pipeline:
-            dev.collect_stats()
+        dev.collect_stats()
         st = M.Stats()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             frame(st)
-            if not args.pipeline:
-                add_stats(tot, st)
         sync()
         elapsed = time.perf_counter() - t0
-        if args.pipeline:
-            dev.collect_stats(st)
-            add_stats(tot, st)
+        dev.collect_stats(st)
+        add_stats(tot, st)
         extra["frames_in_flight"] = nbuf
         if args.save_png:
             frame_host = np.zeros((H, W, 3))
@@ -257,12 +252,14 @@ def run_capi(args):
         print("scene on %d GPU(s) %.2f s" % (n, time.perf_counter() - t_dev), file=sys.stderr)
         st = M.Stats()
         for _ in range(args.warmup):
-            md.render_device(args.spp, args.seed, stats=st)
+            md.render_device(args.spp, args.seed, flags=M.RENDER_KEEP_STATS)
+        md.collect_stats()                            # (discard what the untimed frames left)
         t0 = time.perf_counter()
         for _ in range(args.steps):                   # every call returns with the frame complete in GPU 0's HBM: all streams synchronised
-            md.render_device(args.spp, args.seed, stats=st)
-            add_stats(tot, st)
+            md.render_device(args.spp, args.seed, flags=M.RENDER_KEEP_STATS)
         elapsed = time.perf_counter() - t0
+        md.collect_stats(st)                          # counters and the event pairs recorded inside the timed region, read after it
+        add_stats(tot, st)
         render_ms, gather_ms, comm_ranks = md.last_timing()
         extra.update({"rccl_ranks": comm_ranks, "gather": "rccl" if gather == M.GATHER_RCCL else "peer",
                       "per_rank_render_ms": [float(x) for x in render_ms], "gather_ms": gather_ms, "frames_in_flight": 1})

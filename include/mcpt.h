@@ -213,6 +213,9 @@ int  mcpt_multi_num_devices(const mcpt_multi*);
 int  mcpt_multi_render(mcpt_multi*, const mcpt_render_params*, double* img, mcpt_stats* stats);
 /* the same, leaving the frame in devices[0]'s HBM: *d_img (owned by the handle, valid until the next call) */
 int  mcpt_multi_render_device(mcpt_multi*, const mcpt_render_params*, double** d_img, mcpt_stats* stats);
+/* With MCPT_RENDER_KEEP_STATS in params->flags the GPUs keep their statistics (stats is left zero; nothing is read back inside the
+ * frame); mcpt_multi_collect_stats sums what has gathered since the last call over the GPUs (ms_trace / ms_total: the slowest GPU's). */
+int  mcpt_multi_collect_stats(mcpt_multi*, mcpt_stats* stats);
 /* How the last frame's time divides (HIP events on each GPU's own stream): render_ms[num_devices] = each rank's render;
  * *gather_ms = from devices[0]'s own render being done to the last rank's pixels being in place in its HBM; *comm_ranks = the
  * number of ranks the RCCL communicator reports (0 with MCPT_GATHER_PEER).  Any pointer may be NULL. */

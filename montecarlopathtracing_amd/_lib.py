@@ -76,7 +76,7 @@ EXPORTS = [
     "mcpt_render", "mcpt_render_device", "mcpt_device_collect_stats", "mcpt_sample_radiance", "mcpt_owned_pixels",
     "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_png_encode_deflate", "mcpt_write_png_deflate", "mcpt_write_pfm",
     "mcpt_checkpoint_save", "mcpt_checkpoint_load", "mcpt_decode_jpeg",
-    "mcpt_multi_create", "mcpt_multi_num_devices", "mcpt_multi_render", "mcpt_multi_render_device", "mcpt_multi_last_timing", "mcpt_multi_free",
+    "mcpt_multi_create", "mcpt_multi_num_devices", "mcpt_multi_render", "mcpt_multi_render_device", "mcpt_multi_last_timing", "mcpt_multi_collect_stats", "mcpt_multi_free",
     "mcpt_render_scene", "mcpt_render_scene_ex", "mcpt_render_scene_opts",
 ]
 
@@ -150,6 +150,7 @@ def lib():
     L.mcpt_multi_render.argtypes = [P, C.POINTER(RenderParams), D, C.POINTER(Stats)]
     L.mcpt_multi_render_device.argtypes = [P, C.POINTER(RenderParams), C.POINTER(P), C.POINTER(Stats)]
     L.mcpt_multi_last_timing.argtypes = [P, D, D, I32]
+    L.mcpt_multi_collect_stats.argtypes = [P, C.POINTER(Stats)]
     L.mcpt_multi_free.argtypes = [P]
     L.mcpt_multi_free.restype = None
     L.mcpt_render_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]

@@ -291,6 +291,12 @@ class MultiDevice:
         check(lib().mcpt_multi_render_device(self._h, C.byref(rp), C.byref(d_img), C.byref(stats) if stats is not None else None))
         return d_img.value
 
+    def collect_stats(self, stats=None):
+        """statistics of every RENDER_KEEP_STATS frame since the last call, summed over the GPUs"""
+        stats = stats if stats is not None else Stats()
+        check(lib().mcpt_multi_collect_stats(self._h, C.byref(stats)))
+        return stats
+
     def last_timing(self):
         """(render_ms per rank, gather_ms, ranks the RCCL communicator reports -- 0 with peer copies) of the last frame"""
         n = self.num_devices

@@ -812,6 +812,13 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
         std::fprintf(stderr, "k_wf_trace: %llu rays, %.3f nodes, %.3f triangles visited, %.3f exact tests per ray (%.1f %% of the visited triangles survive the pre-test)\n",
                      c.trace_rays, per(c.trace_nodes, c.trace_rays), per(c.trace_tris, c.trace_rays), per(c.trace_exact, c.trace_rays), 100.0 * per(c.trace_exact, c.trace_tris));
         std::fprintf(stderr, "rays deferred to the exact walk by k_wf_trace: %llu of %llu\n", c.pad[12], c.trace_rays);
+        if (c.pad[20]) {
+            std::fprintf(stderr, "PRE-TEST SELF-CHECK: %llu rejected triangles are candidates by the exact test\n", c.pad[20]);
+            double g[24]; std::memcpy(g, c.dbg, sizeof g);
+            std::fprintf(stderr, "  first: margins beta %.6g gamma %.6g alpha %.6g behind %.6g beyond %.6g clear %.6g | t32 %.9g |det| %.6g | t_k %.17g leader %.17g limit_f %.9g margin %.6g eta4 %.6g slot %.0f of %.0f\n"
+                                 "  ray o %.17g %.17g %.17g d %.17g %.17g %.17g\n",
+                         g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[15], g[16], g[17], g[18], g[19], g[20], g[21]);
+        }
         if (c.pad[13]) std::fprintf(stderr, "finish diag: longest wave %llu steps, %.0f us alive, %.0f us of it in the ray walks (100 MHz ticks; maxima over waves and launches)\n",
                                     c.pad[13], double(c.pad[14]) / 100.0, double(c.pad[15]) / 100.0);
         const double lt = double(c.pad[16] + c.pad[17] + c.pad[18]);

@@ -127,6 +127,8 @@ struct Work {
     uint32_t nodes, tris;       // compressed nodes stepped on, triangles visited (persistent engine: put through the pre-test)
     uint32_t rays = 0;          // rays started by the persistent engine
     uint32_t exact = 0;         // persistent engine: triangles that needed the reference's fp64 test
+    unsigned long long* dbg = nullptr;      // MCPT_PRE_CHECK builds: 24 words for the first offending triangle
+    uint32_t pre_wrong = 0;     // MCPT_PRE_CHECK builds: triangles the pre-test rejected although the exact test makes them candidates (must be 0)
 #ifdef MCPT_TRACE_DIAG
     // [0..5] iterations and waiting lanes of the inner / pre-test / exact phase, [6] idle lanes, [8..11] cycles in refill / inner / pre-test / exact
     unsigned long long diag[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -66,6 +66,7 @@ struct alignas(16) DTriPre {
     float e1[3], a2;
     float e2[3], pad;
 };
+static_assert(sizeof(DTriPre) == 48, "three 16-byte loads");
 
 struct DFast {
     const CwNode* cw;          // compressed wide hierarchy (root = 0)
@@ -125,6 +126,7 @@ struct DCounters {
     unsigned long long shadow_skipped;   // shadow rays the reference traces although their result is never used (light behind the surface)
     unsigned long long trace_rays, trace_nodes, trace_tris;   // work done inside the dominant kernel (k_wf_trace) only
     unsigned long long trace_exact;                           // ... triangles of those that survived the pre-test (exact fp64 tests)
+    unsigned long long dbg[24];   // MCPT_PRE_CHECK builds: what the pre-test saw of the first triangle it should not have rejected
     unsigned long long pad[24];   // diagnostics: [0..11] trace engine (MCPT_TRACE_DIAG builds), [12] rays k_wf_trace handed to the exact walk,
                                   // [13..15] finishing kernel, [16..19] logic kernel
 };

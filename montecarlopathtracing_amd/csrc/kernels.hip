@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(256, WAVES) k_trace_persistent(DScene S, Src s
     Work w = {0, 0};
     trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
     ls.nodes = w.nodes; ls.tris = w.tris;
+    { const unsigned long long tw = wave_sum(w.pre_wrong); if ((threadIdx.x & 63) == 0 && tw && ctr) atomicAdd(&ctr->pad[20], tw); }
     flush_stats(ctr, ls);
 }
 

@@ -307,6 +307,7 @@ int mcpt_multi_render_device(mcpt_multi* m, const mcpt_render_params* p, double*
     HIP_OR_FAIL(hipSetDevice(R0.ordinal));
     HIP_OR_FAIL(hipEventRecord(m->ev0, R0.stream));
     const bool rccl = m->gather == MCPT_GATHER_RCCL && world > 1;
+    const bool keep = (p->flags & MCPT_RENDER_KEEP_STATS) != 0 && !(p->flags & MCPT_RENDER_MEGAKERNEL);
     // one thread per GPU: render the rank's tiles, pack them, (peer mode) send them to devices[0]
     auto work = [&](int r) {
         Rank& R = m->ranks[size_t(r)];
@@ -316,7 +317,10 @@ int mcpt_multi_render_device(mcpt_multi* m, const mcpt_render_params* p, double*
         hipError_t e = hipSetDevice(R.ordinal);
         if (e == hipSuccess) e = hipEventRecord(R.ev_start, R.stream);
         if (e != hipSuccess) { R.rc = MCPT_ERR_HIP; R.err = std::string("multi-device render: ") + hipGetErrorString(e); return; }
-        R.rc = mcpt_render_device(R.dev, &q, R.d_frame, &R.stats, R.stream);
+        // MCPT_RENDER_KEEP_STATS: the ranks' statistics stay on their devices (no read-back, no event queries inside the frame) until
+        // mcpt_multi_collect_stats; one frame at a time all the same (MCPT_RENDER_PIPELINE is not passed on)
+        q.flags &= ~MCPT_RENDER_PIPELINE;
+        R.rc = mcpt_render_device(R.dev, &q, R.d_frame, keep ? nullptr : &R.stats, R.stream);
         if (R.rc) { R.err = mcpt_last_error(); return; }
         e = hipSetDevice(R.ordinal);
         if (e == hipSuccess) e = hipEventRecord(R.ev_rendered, R.stream);
@@ -355,7 +359,7 @@ int mcpt_multi_render_device(mcpt_multi* m, const mcpt_render_params* p, double*
     }
     HIP_OR_FAIL(hipEventRecord(m->ev1, R0.stream));
     HIP_OR_FAIL(hipStreamSynchronize(R0.stream));
-    if (stats) {
+    if (stats && !keep) {
         for (const Rank& R : m->ranks) {
             const mcpt_stats& s = R.stats;
             stats->rays_primary += s.rays_primary; stats->rays_shadow += s.rays_shadow; stats->rays_bounce += s.rays_bounce;
@@ -395,6 +399,27 @@ int mcpt_multi_last_timing(const mcpt_multi* m, double* render_ms, double* gathe
         int n = 0;
         if (!m->comms.empty() && m->comms[0] && m->rccl.CommCount) (void)m->rccl.CommCount(m->comms[0], &n);
         *comm_ranks = n;
+    }
+    return MCPT_OK;
+}
+
+// statistics of every MCPT_RENDER_KEEP_STATS frame since the last call, summed over the GPUs (ms_trace, ms_total: the slowest GPU's sums)
+int mcpt_multi_collect_stats(mcpt_multi* m, mcpt_stats* stats)
+{
+    if (!m || !stats) return fail(MCPT_ERR_ARG, "null argument");
+    std::memset(stats, 0, sizeof *stats);
+    for (Rank& R : m->ranks) {
+        mcpt_stats s{};
+        const int rc = mcpt_device_collect_stats(R.dev, &s);
+        if (rc) return rc;
+        stats->rays_primary += s.rays_primary; stats->rays_shadow += s.rays_shadow; stats->rays_bounce += s.rays_bounce;
+        stats->node_visits += s.node_visits; stats->tri_tests += s.tri_tests; stats->shade_calls += s.shade_calls;
+        stats->samples += s.samples; stats->shadow_skipped += s.shadow_skipped;
+        stats->dom_rays += s.dom_rays; stats->dom_node_visits += s.dom_node_visits; stats->dom_tri_tests += s.dom_tri_tests;
+        stats->launches += s.launches;
+        stats->ms_trace = std::max(stats->ms_trace, s.ms_trace);
+        stats->ms_total = std::max(stats->ms_total, s.ms_total);
+        stats->max_depth = std::max(stats->max_depth, s.max_depth);
     }
     return MCPT_OK;
 }

@@ -203,7 +203,7 @@ __device__ __forceinline__ PreRay make_pre_ray(const DFast& F, const Ray& r, con
     q.margin = margin_ru;
     return q;
 }
-__device__ __forceinline__ bool tri_pre_reject(const DTriPre* __restrict__ q, const PreRay& R, float limit_f)
+__device__ __forceinline__ bool tri_pre_reject(const DTriPre* __restrict__ q, const PreRay& R, float limit_f, float* dbg = nullptr)
 {
     const float4* w = reinterpret_cast<const float4*>(q);
     const float4 A = w[0], B = w[1], C = w[2];             // v0 a1 | e1 a2 | e2 -
@@ -225,6 +225,8 @@ __device__ __forceinline__ bool tri_pre_reject(const DTriPre* __restrict__ q, co
     const bool clear = Dt > 0x1p-9f * X;                    // (i); false as well when a1 = +inf or anything is NaN
     bool rej = U < -Eu || V < -Ev || (U + V) - Dt > (Eu + Ev) + 0x1p-19f * X;
     rej = rej || TQ + Etq < -((R.margin * Dt) * 1.002f) || TQ - Etq > (limit_f * Dt) * 1.002f;
+    if (dbg) { dbg[0] = U + Eu; dbg[1] = V + Ev; dbg[2] = ((Eu + Ev) + 0x1p-19f * X) - ((U + V) - Dt); dbg[3] = TQ + Etq + (R.margin * Dt) * 1.002f;
+               dbg[4] = (limit_f * Dt) * 1.002f - (TQ - Etq); dbg[5] = Dt - 0x1p-9f * X; dbg[6] = TQ / Dt; dbg[7] = Dt; }
     return clear && rej;
 }
 

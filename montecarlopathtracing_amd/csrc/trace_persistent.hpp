@@ -55,7 +55,7 @@ namespace mcpt {
 #define MCPT_EXACT_MIN 1            /* MCPT_LEAF_CLASS: lanes holding a survivor before a leaf iteration runs its exact block */
 #endif
 #ifndef MCPT_PRE_UNROLL
-#define MCPT_PRE_UNROLL 2
+#define MCPT_PRE_UNROLL 2           /* triangles per round of the pre-test (their records are requested together) */
 #endif
 #ifndef MCPT_PRE_TEST
 #define MCPT_PRE_TEST 1             /* 0: every visited triangle survives the pre-test (A/B runs; same results) */
@@ -88,7 +88,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     // behind the rays: three work counters of the wave (nodes, rays, exact tests), bumped by lane 0 with fire-and-forget LDS adds --
     // as scalars the compiler kept them in scratch memory, as per-lane registers they cost three VGPRs the walk does not have
     unsigned int* __restrict__ wctr = reinterpret_cast<unsigned int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
-    if (lane < 3) wctr[lane] = 0u;
+    if (lane < 4) wctr[lane] = 0u;
 
     // wave-uniform supply state
     long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk
@@ -312,6 +312,28 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                         if (k < tri_m && !rej) surv |= 1u << k;
                     }
                 }
+#ifdef MCPT_PRE_CHECK
+                // self-check build: every REJECTED triangle through the exact test as well; one that passes it with a positive t_k not
+                // behind the leader should have survived (counted, and made to survive)
+                for (int k = 0; k < tri_m; k++) {
+                    if ((surv >> k) & 1u) continue;
+                    V3 pc;
+                    if (tri_hit(tris + cur + k, r, pc)) {
+                        const double tc = (pc.x - r.o.x) / r.d.x;
+                        if (tc > 0.0 && (!found || tc <= best_t * (1.0 + 0x1p-40))) {
+                            atomicAdd(&wctr[3], 1u); surv |= 1u << k;
+                            if (w.dbg && atomicCAS(w.dbg, 0ull, 1ull) == 0ull) {      // the first one: what the pre-test saw
+                                float h[8];
+                                (void)tri_pre_reject(pre + cur + k, pr, limit_f, h);
+                                double* o = reinterpret_cast<double*>(w.dbg);
+                                for (int i = 0; i < 8; i++) o[1 + i] = h[i];
+                                o[9] = tc; o[10] = found ? best_t : -1.0; o[11] = limit_f; o[12] = pr.margin; o[13] = pr.eta4; o[14] = cur + k; o[15] = tri_m;
+                                o[16] = r.o.x; o[17] = r.o.y; o[18] = r.o.z; o[19] = r.d.x; o[20] = r.d.y; o[21] = r.d.z;
+                            }
+                        }
+                    }
+                }
+#endif
 #else
                 w.tris += tri_m;
                 surv = (1u << tri_m) - 1u;
@@ -366,7 +388,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         }
     }
     if (slot >= 0) finish_ray();
-    if (lane == 0) { w.nodes += wctr[0]; w.rays += wctr[1]; w.exact += wctr[2]; }     // (summed over the wave by the caller)
+    if (lane == 0) { w.nodes += wctr[0]; w.rays += wctr[1]; w.exact += wctr[2]; w.pre_wrong += wctr[3]; }     // (summed over the wave by the caller)
 }
 
 // second pass: the deferred rays, one lane each, reference-shaped walk.  If more rays were deferred than the side list

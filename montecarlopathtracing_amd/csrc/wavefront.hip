@@ -298,6 +298,9 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_trace(DScene S, WfArgs a, Tra
     WfRaySource src; src.a = a; src.n_paths = n_paths;
     LaneStats ls;
     Work w = {0, 0};
+#ifdef MCPT_PRE_CHECK
+    if (a.ctr) w.dbg = a.ctr->dbg;
+#endif
     trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
     ls.nodes = w.nodes; ls.tris = w.tris;
     if (a.ctr) {        // the dominant kernel's own work, for its roofline
@@ -305,6 +308,8 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_trace(DScene S, WfArgs a, Tra
         if ((threadIdx.x & 63) == 0 && tr) {
             atomicAdd(&a.ctr->trace_nodes, tn); atomicAdd(&a.ctr->trace_tris, tt); atomicAdd(&a.ctr->trace_rays, tr); atomicAdd(&a.ctr->trace_exact, te);
         }
+        const unsigned long long tw = wave_sum(w.pre_wrong);
+        if ((threadIdx.x & 63) == 0 && tw) atomicAdd(&a.ctr->pad[20], tw);
     }
 #ifdef MCPT_TRACE_DIAG
     if ((threadIdx.x & 63) == 0 && a.ctr) for (int i = 0; i < 12; i++) atomicAdd(&a.ctr->pad[i], w.diag[i]);
