@@ -283,6 +283,9 @@ __device__ __forceinline__ CwHits cw_step(const CwNode* __restrict__ nd, const R
     return h;
 }
 
+#ifndef MCPT_LANE_PRE_TEST
+#define MCPT_LANE_PRE_TEST 0           /* the pre-test in the one-lane walk too: measured, no difference (the finishing kernel is bound by its chain of dependent steps, 15.51 vs 15.52 ms per 1/8 frame) */
+#endif
 // One ray per lane, start to finish (while-while over the compressed hierarchy): the same decisions, in the same order
 // per candidate, as the persistent engine -- used where only a few thousand rays remain and a launch per bounce would
 // cost more than the rays themselves.  stack: this lane's LDS words, stack[i * stride].
@@ -315,10 +318,28 @@ __device__ __forceinline__ bool trace_lane_fast(const DScene& S, const Ray& r, H
         if (cur == MCPT_FAST_EMPTY) break;
         const int ref = -1 - cur;
         const int first = ref >> 4, count = (ref & 7) + 1;
-        for (int i = 0; i < count; i++) {
+        // the leaf's triangles through the conservative fp32 pre-test first (tri_pre_reject: their records are requested together,
+        // one memory latency for the whole leaf), the reference's test for the survivors only
+        unsigned int surv = 0;
+#if MCPT_LANE_PRE_TEST
+        {
+            const PreRay pr = make_pre_ray(F, r, rf.o, __double2float_ru(margin));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {        // (a slot past the leaf's last is the next leaf's or the array's padding: tested, not used)
+                const bool rej = tri_pre_reject(F.pre + first + i, pr, limit_f);
+                if (i < count && !rej) surv |= 1u << i;
+            }
+            for (int i = 4; i < count; i++) if (!tri_pre_reject(F.pre + first + i, pr, limit_f)) surv |= 1u << i;
+        }
+#else
+        surv = (1u << count) - 1u;
+#endif
+        w.tris += count;
+        while (surv) {
+            const int i = __ffs(surv) - 1;
+            surv &= surv - 1;
             const DTri* tr = tris + first + i;
             V3 p;
-            w.tris++;
             if (!tri_hit(tr, r, p)) continue;
             double t; int k;
             if (better_candidate(tr, r, rcp, p, found, best, t, k)) {

@@ -61,8 +61,11 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
 {
     const long long n_prev = (long long)a.counts_in->n_next * a.count_mul;
     if (!FIRST && n_prev <= (long long)a.finish_below) return;         // those paths went to k_wf_finish
-    __shared__ unsigned int wave_tot[4];
-    __shared__ unsigned int block_base;
+    // (two sets, used in turn: the values of one block iteration are still being read by its slower waves while the faster ones
+    // write the next iteration's -- with one set that took a third barrier per iteration)
+    __shared__ unsigned int wave_tot[2][4];
+    __shared__ unsigned int block_base[2];
+    int turn = 0;
     const long long cap = a.cap;
     const int nl = a.nl;
     // One light (the usual scene): T * c and T * w / P_RR are formed when the vertex is shaded instead of when it is resolved --
@@ -173,18 +176,18 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         {
         const unsigned long long bal = __ballot(alive);
         const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wv] = (unsigned int)__popcll(bal);
+        turn ^= 1;
+        if (lane == 0) wave_tot[turn][wv] = (unsigned int)__popcll(bal);
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned int tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            const unsigned int tot = wave_tot[turn][0] + wave_tot[turn][1] + wave_tot[turn][2] + wave_tot[turn][3];
             // (one atomic per 256 paths on one word: with the word sharded 16 ways this kernel's first pass takes 6.0 instead of 6.5 ms --
             // the counter is not its floor)
-            block_base = tot ? atomicAdd(&a.counts->n_next, tot) : 0u;
+            block_base[turn] = tot ? atomicAdd(&a.counts->n_next, tot) : 0u;
         }
         __syncthreads();
-        unsigned int off = block_base + before;
-        for (int q = 0; q < wv; q++) off += wave_tot[q];
-        __syncthreads();
+        unsigned int off = block_base[turn] + before;
+        for (int q = 0; q < wv; q++) off += wave_tot[turn][q];
         MCPT_LSTAMP(1)
         if (!alive) continue;
         j = off;

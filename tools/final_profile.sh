@@ -28,6 +28,11 @@ for n in 2 4 8; do
   timeout -k 10 120 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sim-world $n > $out/sim_world_$n.json 2>> $out/bench.err
   python3 -c "import json; d=json.load(open('$out/sim_world_$n.json')); print('sim-world $n', round(d['ms_per_step'],3), 'ms')"
 done
+# every rank's share of the 8-way partition, rendered alone (the slowest one is what an 8-GPU frame waits for, before the exchange)
+for r in 0 1 2 3 4 5 6 7; do
+  timeout -k 10 120 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sim-world 8 --sim-rank $r > $out/sim8_rank$r.json 2>> $out/bench.err
+  python3 -c "import json; d=json.load(open('$out/sim8_rank$r.json')); print('sim-world 8 rank $r', round(d['ms_per_step'],3), 'ms')"
+done
 timeout -k 10 200 python3 bench.py --scene veach-mis --spp 100 --steps 5 --no-cpu-baseline > $out/veach_mis_spp100.json 2>> $out/bench.err
 timeout -k 10 300 python3 bench.py --scene interior --steps 3 --no-cpu-baseline > $out/interior_spp256.json 2>> $out/bench.err
 timeout -k 10 400 python3 bench.py --scene synthetic --spp 16 --steps 3 --no-cpu-baseline > $out/synthetic10m_spp16.json 2>> $out/bench.err

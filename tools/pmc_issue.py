@@ -8,6 +8,17 @@ import json
 import sys
 from collections import defaultdict
 
+
+def build_id():
+    """hash of the sources the loaded libmcpt.so was compiled from (bench.py quotes a profile only for the build that made it)"""
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    try:
+        import montecarlopathtracing_amd as M
+        return M.build_id()
+    except Exception as e:      # noqa: BLE001
+        return "unknown (%s)" % e
+
 d, sub, out, cmd = sys.argv[1:5]
 acc = defaultdict(float)
 disp = set()
@@ -18,7 +29,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             disp.add(row["Dispatch_Id"])
 xcds, simds = 8, 1024
 cycles = acc["GRBM_GUI_ACTIVE"] / xcds
-rec = {"kernel": sub, "command": cmd, "dispatches_counted": len(disp),
+rec = {"kernel": sub, "build_id": build_id(), "command": cmd, "dispatches_counted": len(disp),
        "valu_wave_instructions": acc["SQ_INSTS_VALU"], "salu_wave_instructions": acc["SQ_INSTS_SALU"],
        "valu_busy": acc["SQ_ACTIVE_INST_VALU"] * 4 / (simds * cycles) if cycles else None,
        "tcp_busy": acc["TCP_GATE_EN2_sum"] / acc["TCP_GATE_EN1_sum"] if acc["TCP_GATE_EN1_sum"] else None,

@@ -8,6 +8,17 @@ import glob
 import json
 import sys
 
+
+def build_id():
+    """hash of the sources the loaded libmcpt.so was compiled from (bench.py quotes a profile only for the build that made it)"""
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    try:
+        import montecarlopathtracing_amd as M
+        return M.build_id()
+    except Exception as e:      # noqa: BLE001
+        return "unknown (%s)" % e
+
 d, kernel, command, out = sys.argv[1:5]
 acc, disp = {}, {}
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -19,7 +30,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         disp.setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])
 n = len(disp["FETCH_SIZE"])
 fetch, write = acc["FETCH_SIZE"] * 1024.0, acc["WRITE_SIZE"] * 1024.0
-json.dump({"kernel": kernel, "command": command, "dispatches": n, "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
+json.dump({"kernel": kernel, "build_id": build_id(), "command": command, "dispatches": n, "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
            "bytes_per_launch": (2.0 * fetch + write) / n, "bytes_per_launch_uncorrected": (fetch + write) / n,
            "note": "separate --pmc passes; KiB -> bytes; FETCH_SIZE doubled (gfx950 wide-stream correction, upper bound here)"},
           open(out, "w"), indent=1)
