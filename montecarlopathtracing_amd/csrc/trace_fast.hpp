@@ -230,6 +230,9 @@ __device__ __forceinline__ bool tri_pre_reject(const DTriPre* __restrict__ q, co
     return clear && rej;
 }
 
+#ifndef MCPT_PARTIAL_SORT
+#define MCPT_PARTIAL_SORT 0
+#endif
 struct CwHits { float key[4]; int ref[4]; };
 
 // One step on a compressed node: which children may contain a candidate, sorted by lower bound of entry distance
@@ -270,6 +273,19 @@ __device__ __forceinline__ CwHits cw_step(const CwNode* __restrict__ nd, const R
         h.key[c] = hit ? entry : __builtin_inff();
         h.ref[c] = hit ? child[c] : MCPT_FAST_EMPTY;
     }
+#if MCPT_PARTIAL_SORT
+    // only the nearest child is brought to the front (three conditional swaps); the other hits keep their slot order
+#define MCPT_CSWAP(i, j)                                                                        \
+    {                                                                                           \
+        const bool sw = h.key[j] < h.key[i];                                                    \
+        const float ka = sw ? h.key[j] : h.key[i], kb = sw ? h.key[i] : h.key[j];               \
+        const int ra = sw ? h.ref[j] : h.ref[i], rb = sw ? h.ref[i] : h.ref[j];                 \
+        h.key[i] = ka; h.key[j] = kb; h.ref[i] = ra; h.ref[j] = rb;                             \
+    }
+    MCPT_CSWAP(0, 1) MCPT_CSWAP(2, 3) MCPT_CSWAP(0, 2)
+#undef MCPT_CSWAP
+    return h;
+#endif
     // sorting network for 4 keys
 #define MCPT_CSWAP(i, j)                                                                        \
     {                                                                                           \

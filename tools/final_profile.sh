@@ -37,4 +37,10 @@ timeout -k 10 200 python3 bench.py --scene veach-mis --spp 100 --steps 5 --no-cp
 timeout -k 10 300 python3 bench.py --scene interior --steps 3 --no-cpu-baseline > $out/interior_spp256.json 2>> $out/bench.err
 timeout -k 10 400 python3 bench.py --scene synthetic --spp 16 --steps 3 --no-cpu-baseline > $out/synthetic10m_spp16.json 2>> $out/bench.err
 timeout -k 10 600 python3 bench.py --scene synthetic --width 3840 --height 2160 --spp 1024 --steps 1 --warmup 0 --no-cpu-baseline > $out/synthetic10m_3840x2160_spp1024.json 2>> $out/bench.err
+# lanes per phase, iterations and the pre-test's share from the in-kernel counters (diagnostic build: variants/libmcpt_diag.so, tools/build_variant.sh diag -DMCPT_TRACE_DIAG)
+if [ -f montecarlopathtracing_amd/csrc/variants/libmcpt_diag.so ]; then
+  MCPT_LIB=montecarlopathtracing_amd/csrc/variants/libmcpt_diag.so MCPT_PRINT_DIAG=1 timeout -k 10 200 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/diag.json 2> $out/diag.err
+  grep -E "trace diag|k_wf_trace:|deferred|logic diag|finish diag" $out/diag.err | tail -5 > $out/trace_phases.txt
+  cat $out/trace_phases.txt
+fi
 for f in veach_mis_spp100 interior_spp256 synthetic10m_spp16 synthetic10m_3840x2160_spp1024; do python3 -c "import json; d=json.load(open('$out/$f.json')); print('$f', round(d['ms_per_step'],2), 'ms', round(d['value'],1), 'Mrays/s', round(d['nodes_per_ray'],1), round(d['tris_per_ray'],1))"; done
