@@ -683,7 +683,14 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         (void)hipFree(d_slots);
         if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("fast triangle gather: ") + hipGetErrorString(e));
     }
-    {
+    // The pre-test pays where the walk is bound by instruction issue, i.e. where nodes and triangles come out of L1 / L2 / the 256-MB
+    // Infinity Cache (cornell-box: 7.38 -> 7.25 ms per k_wf_trace launch; veach-mis and the 204 k-triangle interior alike).  On the
+    // 10 M-triangle scene the walk waits for memory, and a second dependent fetch per leaf (48-B record, then the 128-B record of a
+    // survivor) costs more than the skipped arithmetic saves: 6.90 vs 6.44 ms per launch.  So: records only for scenes of at most
+    // MCPT_PRE_TEST_MAX_TRIS triangles (default 2^20: ~200 B per triangle of nodes, records and triangles stay cache-resident).
+    long long pre_max = 1ll << 20;
+    if (const char* e = std::getenv("MCPT_PRE_TEST_MAX_TRIS")) pre_max = std::atoll(e);
+    if (t <= pre_max) {
         // fp32 records of the triangle phase's pre-test, one per slot of the fast triangle array
         const int n_slots = fast_on_device ? t : int(fb_ro.leaf_tris.size());
         // (four records of padding: the pre-test reads its triangles in rounds of up to four slots, used or not)

@@ -338,7 +338,8 @@ __device__ __forceinline__ bool trace_lane_fast(const DScene& S, const Ray& r, H
         // one memory latency for the whole leaf), the reference's test for the survivors only
         unsigned int surv = 0;
 #if MCPT_LANE_PRE_TEST
-        {
+        if (!F.pre) surv = (1u << count) - 1u;
+        else {
             const PreRay pr = make_pre_ray(F, r, rf.o, __double2float_ru(margin));
 #pragma unroll
             for (int i = 0; i < 4; i++) {        // (a slot past the leaf's last is the next leaf's or the array's padding: tested, not used)

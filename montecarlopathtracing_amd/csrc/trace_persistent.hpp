@@ -299,8 +299,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
             if (state == ST_TRI) {
                 unsigned int surv = 0;
 #if MCPT_PRE_TEST
-                const PreRay pr = make_pre_ray(F, r, rf.o, margin_f);
                 w.tris += tri_m;
+                if (!pre) surv = (1u << tri_m) - 1u;       // scenes for which the pre-test is switched off (capi.cpp: too large for the caches)
+                else {
+                const PreRay pr = make_pre_ray(F, r, rf.o, margin_f);
                 // MCPT_PRE_UNROLL triangles per round: their records are requested together, so a round costs one memory latency
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (int k0 = 0; k0 < tri_m; k0 += MCPT_PRE_UNROLL) {
@@ -334,6 +336,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                     }
                 }
 #endif
+                }
 #else
                 w.tris += tri_m;
                 surv = (1u << tri_m) - 1u;
