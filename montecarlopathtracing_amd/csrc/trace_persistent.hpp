@@ -85,10 +85,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
     const long long small = chunk < MCPT_TAIL_CHUNK ? chunk : MCPT_TAIL_CHUNK;
     const long long big_tickets = (total - total / 8) / chunk;
     const int lane = threadIdx.x & 63;
-    // behind the rays: three work counters of the wave (nodes, rays, exact tests), bumped by lane 0 with fire-and-forget LDS adds --
-    // as scalars the compiler kept them in scratch memory, as per-lane registers they cost three VGPRs the walk does not have
+    // work counters that are the same for every lane of a phase: wave-uniform, in scalar registers (per-lane they would cost three
+    // VGPRs the walk does not have); wctr: a few LDS words behind the rays for the rare per-lane corrections
+    unsigned int c_nodes = 0, c_rays = 0, c_exact = 0;
     unsigned int* __restrict__ wctr = reinterpret_cast<unsigned int*>(raybuf + MCPT_RAYBUF_DOUBLES * 64);
-    if (lane < 4) wctr[lane] = 0u;
+    if (lane < 4) wctr[lane] = 0u;        // [0] inner steps refused (stack full), [3] MCPT_PRE_CHECK
 
     // wave-uniform supply state
     long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk
@@ -238,7 +239,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
                     }
                 }
                 lds_taken += give;
-                { const unsigned int n_started = (unsigned int)__popcll(__ballot(started)); if (lane == 0 && n_started) atomicAdd(&wctr[1], n_started); }
+                c_rays += (unsigned int)__popcll(__ballot(started));
             }
         }
         // ------------------------------------------------------------------ pick the phase most lanes wait for
@@ -270,10 +271,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         if (phase == ST_INNER) {
             // -------------------------------------------------------------- one step on a compressed node
             // three pushes must fit: a ray whose stack would overflow (the hierarchy is built not to need that) goes to the exact walk
-            const bool over = state == ST_INNER && sp > stack_cap - 3;
-            { const unsigned int n_step = (unsigned int)(n_inner - __popcll(__ballot(over))); if (lane == 0) atomicAdd(&wctr[0], n_step); }
+            c_nodes += (unsigned int)n_inner;
             if (state == ST_INNER) {
-                if (over) { ambiguous = true; state = ST_IDLE; }
+                if (sp > stack_cap - 3) { ambiguous = true; state = ST_IDLE; atomicAdd(&wctr[0], 1u); }       // (not a step: taken off the count)
                 else {
                     const CwHits h = cw_step(nodes + cur, rf, limit_f);
                     // nearest first; the others go on the stack so that the next nearest is on top
@@ -350,10 +350,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         // members of the leaf class, for the next leaf iteration
         const int n_hold = phase == ST_TRI ? __popcll(__ballot(state == ST_EXACT)) : 0;
         if (n_hold >= MCPT_EXACT_MIN || (n_hold && (!n_tri || n_hold >= n_tri + n_exact))) {
-            if (lane == 0) atomicAdd(&wctr[2], (unsigned int)n_hold);
+            c_exact += (unsigned int)n_hold;
 #else
         else if (phase == ST_EXACT) {
-            if (lane == 0) atomicAdd(&wctr[2], (unsigned int)n_exact);
+            c_exact += (unsigned int)n_exact;
 #endif
             // -------------------------------------------------------------- one surviving triangle through the reference's test
             if (state == ST_EXACT) {
@@ -391,7 +391,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
         }
     }
     if (slot >= 0) finish_ray();
-    if (lane == 0) { w.nodes += wctr[0]; w.rays += wctr[1]; w.exact += wctr[2]; w.pre_wrong += wctr[3]; }     // (summed over the wave by the caller)
+    if (lane == 0) { w.nodes += c_nodes - wctr[0]; w.rays += c_rays; w.exact += c_exact; w.pre_wrong += wctr[3]; }     // (summed over the wave by the caller)
 }
 
 // second pass: the deferred rays, one lane each, reference-shaped walk.  If more rays were deferred than the side list
