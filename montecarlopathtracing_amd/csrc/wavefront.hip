@@ -12,6 +12,9 @@
 
 namespace mcpt {
 
+#ifndef MCPT_FINISH_WAVES
+#define MCPT_FINISH_WAVES 2  /* blocks of the finishing kernel per CU the compiler plans for: 2 = 256 registers per lane (76 bytes of them in scratch memory), 1 = 512 */
+#endif
 #ifndef MCPT_LOGIC_WAVES
 #define MCPT_LOGIC_WAVES 4   /* waves per SIMD the logic kernel is compiled for: 128 VGPRs, 20 / 40 spilled registers.  Round 1 (ms per frame): 2: 111.5,
                                3: 108.0, 4: 107.2, 5: 113.5, 6: 121.2; with the 4-wave trace engine: 3: 101.6, 4: 100.4 (cornell-box), equal within
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_reference(DScene S, WfArgs a)
 // take the next unclaimed path (one atomic per refill on the pass's own count slot), so a wave is as long as its share of
 // the work, not as its longest path.  A lane that has just adopted a path finds the rays of its first step in the wavefront
 // state instead of computing them; from the second step on everything lives in registers.
-__global__ void __launch_bounds__(256, 2) k_wf_finish(DScene S, WfArgs a)
+__global__ void __launch_bounds__(256, MCPT_FINISH_WAVES) k_wf_finish(DScene S, WfArgs a)
 {
     __shared__ int lds_stack[MCPT_FAST_STACK * 256];
     const long long n = a.counts->n_next;
