@@ -9,11 +9,12 @@ cp $t/issue_utilisation.json ${p}_issue_utilisation.json
 cp $t/pmc_hbm_traffic.txt ${p}_pmc_hbm_traffic.txt
 cp $t/pmc_sq/summary.txt ${p}_pmc_sq_tcp.txt
 cp $t/timeline_one_eighth.txt ${p}_timeline_one_eighth_frame.txt
+[ -f $t/trace_phases.txt ] && cp $t/trace_phases.txt ${p}_trace_phases.txt
 python3 - $t ${p}_other_configs.json <<'PY'
 import json, sys
 t, out = sys.argv[1:3]
 rec = {}
-for name in ("sim_world_2", "sim_world_4", "sim_world_8", "veach_mis_spp100", "interior_spp256", "synthetic10m_spp16", "synthetic10m_3840x2160_spp1024"):
+for name in ("sim_world_2", "sim_world_4", "sim_world_8", "sim8_rank0", "sim8_rank1", "sim8_rank2", "sim8_rank3", "sim8_rank4", "sim8_rank5", "sim8_rank6", "sim8_rank7", "veach_mis_spp100", "interior_spp256", "synthetic10m_spp16", "synthetic10m_3840x2160_spp1024"):
     try:
         d = json.load(open("%s/%s.json" % (t, name)))
     except Exception as e:
@@ -21,6 +22,7 @@ for name in ("sim_world_2", "sim_world_4", "sim_world_8", "veach_mis_spp100", "i
         continue
     rec[name] = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "rays_per_frame", "nodes_per_ray", "tris_per_ray", "config")}
     rec[name]["roofline"] = {k: d["roofline"][k] for k in ("achieved", "frac", "avg_launch_ms", "launches", "record_bytes_rate_GBs")}
+    rec[name]["build_id"] = d.get("build_id")
 json.dump(rec, open(out, "w"), indent=1)
 PY
 ls -la ${p}_*
