@@ -211,7 +211,7 @@ def run_capi(args):
 
         def frame(stats):
             t = turn[0] = (turn[0] + 1) % nbuf
-            dev.render_device(bufs[t].ptr.value, args.spp, args.seed, rank, world, flags=flags, stats=None, stream=streams[t].h.value)
+            dev.render_device(bufs[t].ptr.value, args.spp, args.seed, rank, world, args.tile_w, args.tile_h, flags=flags, stats=None, stream=streams[t].h.value)
             if not args.pipeline:
                 streams[t].synchronize()
 
@@ -252,11 +252,11 @@ def run_capi(args):
         print("scene on %d GPU(s) %.2f s" % (n, time.perf_counter() - t_dev), file=sys.stderr)
         st = M.Stats()
         for _ in range(args.warmup):
-            md.render_device(args.spp, args.seed, flags=M.RENDER_KEEP_STATS)
+            md.render_device(args.spp, args.seed, args.tile_w, args.tile_h, flags=M.RENDER_KEEP_STATS)
         md.collect_stats()                            # (discard what the untimed frames left)
         t0 = time.perf_counter()
         for _ in range(args.steps):                   # every call returns with the frame complete in GPU 0's HBM: all streams synchronised
-            md.render_device(args.spp, args.seed, flags=M.RENDER_KEEP_STATS)
+            md.render_device(args.spp, args.seed, args.tile_w, args.tile_h, flags=M.RENDER_KEEP_STATS)
         elapsed = time.perf_counter() - t0
         md.collect_stats(st)                          # counters and the event pairs recorded inside the timed region, read after it
         add_stats(tot, st)
@@ -365,6 +365,8 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="one GPU, diagnostic: two frames in flight on two streams (a step is then 1/throughput, not a latency)")
     ap.add_argument("--sim-world", type=int, default=0, help="one GPU, diagnostic: render only one rank's tiles of an N-rank partition")
     ap.add_argument("--sim-rank", type=int, default=0, help="with --sim-world: which rank's tiles")
+    ap.add_argument("--tile-w", type=int, default=0, help="tile width of the rank partition (0: the library's default, 32)")
+    ap.add_argument("--tile-h", type=int, default=0, help="tile height of the rank partition (0: the library's default, 8)")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: libraries that print banners to file descriptor 1 (RCCL's version block, Gloo's connection chatter)

@@ -1,6 +1,7 @@
-"""A few HIP runtime calls through ctypes, for GPU tests that need streams and device buffers without importing torch (torch
-bundles its own copy of the HIP runtime: imported AFTER libmcpt.so has loaded /opt/rocm's, it finds no GPU; bench.py imports it
-first).  The library handle resolves to the runtime libmcpt.so already loaded."""
+"""A few HIP runtime calls through ctypes, for GPU tests and bench.py's one-GPU diagnostics that need streams and device buffers
+without torch (the torch wheel bundles its own copy of the HIP runtime under the same soname: whichever copy is loaded first is the one
+libmcpt.so runs on -- INTEGRATION.md section 1 -- so the GPU test process and bench.py's default path keep torch out).  The library
+handle resolves to the runtime libmcpt.so has already loaded."""
 import ctypes as C
 
 import numpy as np
