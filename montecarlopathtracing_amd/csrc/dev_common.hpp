@@ -122,7 +122,10 @@ __device__ __forceinline__ V3 barycentric(V3 v1, V3 v2, V3 v3, V3 p)
     return mk(dot(cross(e1, d3), n) / an, dot(cross(e2, d1), n) / an, dot(cross(e3, d2), n) / an);
 }
 
-struct Hit { int leaf; double t; V3 p; };
+struct Hit {
+    int leaf; double t; V3 p;
+    int mat = -1;       // material of the hit triangle where the walk has it at hand (the persistent engine: same record as `leaf`), else -1
+};
 struct Work {
     uint32_t nodes, tris;       // compressed nodes stepped on, triangles visited (persistent engine: put through the pre-test)
     uint32_t rays = 0;          // rays started by the persistent engine

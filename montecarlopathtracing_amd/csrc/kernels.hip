@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(256) k_trace_closest_reference(DScene S, const
 
 // ---- persistent fast walk over a plain ray array (mcpt_trace_closest) and over the primary rays
 struct ArrayRaySource {
+    static constexpr bool kWantsPoint = true;
     const double* rays; long long n;
     int32_t* leaf_out; double* t_out; double* p_out;     // leaf_out receives the LEAF index; k_finish_hits turns it into a face
     __device__ __forceinline__ long long total() const { return n; }
@@ -54,6 +55,7 @@ struct ArrayRaySource {
 };
 
 struct PrimaryRaySource {
+    static constexpr bool kWantsPoint = true;
     const double* dirs; const int32_t* pixels; int n_pixels; double eye[3]; PrimaryHit* hits;
     __device__ __forceinline__ long long total() const { return n_pixels; }
     __device__ __forceinline__ bool fetch(long long q, Ray& r) const

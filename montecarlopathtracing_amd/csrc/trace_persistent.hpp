@@ -64,6 +64,7 @@ namespace mcpt {
 // Src must provide:  long long total() const;
 //                    bool fetch(long long q, Ray& r) const;        // false: slot holds no ray (loads may be speculative)
 //                    void store(long long q, bool hit, const Hit& h) const;
+//                    static constexpr bool kWantsPoint;             // false: store() does not look at h.p
 //
 // Ray supply: when the wave's LDS batch is used up, the next 64 slots of its chunk are fetched at once (one slot per lane,
 // branch-free, so nothing waits on a flag) into LDS ([component][lane], 52 B per ray); idle lanes take entries by ballot rank.
@@ -128,12 +129,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, const Src& src
             const DTri* tr = tris + best_leaf;
             if (!own_box_hit(tr, r, rc)) ambiguous = true;
             h.leaf = tr->leaf;
+            h.mat = tr->material;
             h.t = (best_px - r.o.x) / r.d.x;                    // pathTracing.cpp:347
-            // the hit point: the first two lines of intersect(Ray&, Face&, Vertex&) again -- the same operations on the same
-            // operands give the same bits as when the triangle was tested
-            const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
-            const double t = dot(v1 - r.o, n) / dot(n, r.d);
-            h.p = r.o + r.d * t;
+            // the hit point, for sources that store it: the first two lines of intersect(Ray&, Face&, Vertex&) again -- the same
+            // operations on the same operands give the same bits as when the triangle was tested
+            if constexpr (Src::kWantsPoint) {
+                const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
+                const double t = dot(v1 - r.o, n) / dot(n, r.d);
+                h.p = r.o + r.d * t;
+            }
         }
         if (ambiguous) {
             const unsigned int at = atomicAdd(&queue->slow_count, 1u);

@@ -34,7 +34,7 @@ __device__ __forceinline__ void stc(double* __restrict__ a, long long cap, long 
 size_t wf_bytes_per_path(int nl)
 {
     const size_t state = 4 + (6 + 3 * nl + (nl == 1 ? 3 : 6)) * 8 + nl * 4 + 4 + nl * 4 + 4 + 3 * 8;   // WfState (no w with one light)
-    const size_t rays = (1 + nl) * 3 * 8;                                            // WfRays
+    const size_t rays = nl * 3 * 8;                                                  // WfRays
     return 2 * state + rays;
 }
 
@@ -50,10 +50,10 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfSta
         s.w = nl == 1 ? nullptr : static_cast<double*>(take(cap * 24)); s.bdir = static_cast<double*>(take(cap * 24));
         s.btype = static_cast<int32_t*>(take(cap * 4));
         s.hit_mat = static_cast<int32_t*>(take(size_t(cap) * 4 * nl)); s.hit_leaf = static_cast<int32_t*>(take(cap * 4));
-        s.hit_p = static_cast<double*>(take(cap * 24));
+        s.p = static_cast<double*>(take(cap * 24));
     };
     state(A); state(B);
-    R.p = static_cast<double*>(take(size_t(cap) * 24)); R.d = static_cast<double*>(take(size_t(cap) * 24 * nl));
+    R.d = static_cast<double*>(take(size_t(cap) * 24 * nl));
     return p <= end;
 }
 
@@ -130,8 +130,11 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                 if (depth > 1) L = ldc(a.in.L, cap, i);
                 V3 wgt = mk(1, 1, 1);
                 if (!folded) wgt = ldc(a.in.w, cap, i);
-                const V3 hp = ldc(a.in.hit_p, cap, i);
                 const V3 bd = ldc(a.in.bdir, cap, i);
+                // the vertex the bounce ray left from: the pixel's primary hit after the first pass, in.p afterwards
+                V3 pv;
+                if (depth == 1) { const PrimaryHit* ph = a.hits + (a.first_slot + id / a.spp); pv = mk(ph->p[0], ph->p[1], ph->p[2]); }
+                else pv = ldc(a.in.p, cap, i);
                 V3 L_dir = mk(0, 0, 0);
                 for (int l = 0; l < nl; l++) {
                     const int expect = a.in.expect[(long long)l * cap + i];
@@ -150,7 +153,15 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
                     L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
                     if (have_vertex) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
                 }
-                if (have_vertex) { leaf = hl; p = hp; dir = neg(bd); in_type = bt & 7; }
+                if (have_vertex) {
+                    // the hit point of the bounce ray, as the reference's test formed it when the trace kernel accepted the triangle
+                    // (sceneManagement.cpp:318-320: t = ((v1 - o) . n) / (n . d), p = o + d t; same operands, same operations)
+                    const V3 ro = (bt & MCPT_BT_NO_OFFSET) ? pv : pv + bd * 0.01;
+                    const DTri* tr = S.tris + hl;
+                    const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
+                    const double t = dot(v1 - ro, n) / dot(n, bd);
+                    leaf = hl; p = ro + bd * t; dir = neg(bd); in_type = bt & 7;
+                }
             }
             if (have_vertex) {
                 ls.shades++;
@@ -219,7 +230,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             a.out.expect[(long long)l * cap + j] = expect;
         }
 
-        if (!FIRST) stc(a.rays.p, cap, j, p);            // first pass: the pixel's primary hit, read from a.hits where needed
+        if (!FIRST) stc(a.out.p, cap, j, p);             // first pass: the pixel's primary hit, read from a.hits where needed
         V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
         const int btype = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
         if (btype >= 0) { stc(a.out.bdir, cap, j, nd); ls.bounce++; }
@@ -239,6 +250,7 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
 // ---------------------------------------------------------------------------------------------- trace kernels
 // ray slot q = l*n_paths + j, l in [0, nl] (l == nl: the bounce ray of path j)
 struct WfRaySource {
+    static constexpr bool kWantsPoint = false;      // results are a leaf or a material: the hit point is formed again by the next logic pass
     WfArgs a;
     long long n_paths;
     __device__ __forceinline__ long long total() const { return n_paths * (a.nl + 1); }
@@ -255,7 +267,7 @@ struct WfRaySource {
             const PrimaryHit* ph = a.hits + (a.first_slot + a.out.id[j] / a.spp);
             return mk(ph->p[0], ph->p[1], ph->p[2]);
         }
-        return ldc(a.rays.p, a.cap, j);
+        return ldc(a.out.p, a.cap, j);
     }
     __device__ __forceinline__ bool fetch(long long q, Ray& r) const
     {
@@ -275,9 +287,9 @@ struct WfRaySource {
         split(q, l, j);
         if (l == a.nl) {
             a.out.hit_leaf[j] = ok ? h.leaf : -1;
-            if (ok) stc(a.out.hit_p, a.cap, j, h.p);
         } else {
-            a.out.hit_mat[(long long)l * a.cap + j] = ok ? a.tris[h.leaf].material : -1;
+            // (the persistent engine hands the material over with the leaf: one dependent fetch less per shadow ray in its store batch)
+            a.out.hit_mat[(long long)l * a.cap + j] = ok ? (h.mat >= 0 ? h.mat : a.tris[h.leaf].material) : -1;
         }
     }
 };

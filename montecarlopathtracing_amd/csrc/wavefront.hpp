@@ -28,15 +28,18 @@ struct WfState {            // one side of the double buffer; every array has `c
     int32_t* btype;         // [cap] ray_type of the bounce ray (| MCPT_BT_NO_OFFSET: it starts at the vertex itself), -1 = none
     // what trace(d) adds:
     int32_t* hit_mat;       // [nl][cap] material of the shadow ray's closest hit, -1 = miss
-    int32_t* hit_leaf;      // [cap]     bounce ray: leaf or -1
-    double* hit_p;          // [3][cap]  bounce ray: hit point
+    int32_t* hit_leaf;      // [cap]     bounce ray: leaf or -1.  The hit point is not stored: the next logic pass forms it again from the
+                            //           ray it rebuilds and the leaf's plane -- the first two lines of the reference's triangle test on the
+                            //           same operands, hence the same bits -- which takes 24 bytes per bounce ray off the trace kernel's
+                            //           scattered stores and ~45 instructions per finished ray off the instruction-bound kernel
+    double* p;              // [3][cap]  the vertex that was shaded (origin of its rays before the 0.01 offset); not stored by the first
+                            //           pass (the pixel's primary hit)
 };
 
 // Rays of vertex d, written by logic(d), consumed by trace(d); slot (l, j), l = nl for the bounce ray.  All rays of a vertex
 // leave from p (+ 0.01 d, pathTracing.cpp:196,128; refraction and total reflection start at p itself, :97,:110), so p is
-// stored once and the origin is rebuilt where the ray is fetched; the bounce direction is WfState::bdir.
+// stored once (WfState::p) and the origin is rebuilt where the ray is fetched; the bounce direction is WfState::bdir.
 struct WfRays {
-    double* p;              // [3][cap]     the shaded vertex
     double* d;              // [nl][3][cap] shadow-ray directions
 };
 
