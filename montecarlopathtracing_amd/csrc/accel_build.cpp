@@ -433,6 +433,36 @@ void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out,
     out.cw_stack_need += lower_need;
 }
 
+// The trace engines mirror the first nodes of the array in LDS (trace_fast.hpp: NodeCache): relabel so that these are the top of the
+// tree, breadth first -- the nodes nearly every ray steps on.  The others keep their relative order.  A walk does not depend on node
+// numbers (children are ordered by entry distance, pushed by slot): same visits, same results.
+static void cw_top_first(std::vector<CwNode>& cw, int n_top)
+{
+    const int n = int(cw.size());
+    if (n <= 1 || n_top <= 1) return;
+    std::vector<int32_t> top;
+    top.reserve(size_t(std::min(n, n_top)));
+    top.push_back(0);
+    for (size_t head = 0; head < top.size() && int(top.size()) < n_top; head++)
+        for (int c = 0; c < 4 && int(top.size()) < n_top; c++) {
+            const int32_t r = cw[size_t(top[head])].child[c];
+            if (r >= 0 && r < n) top.push_back(r);
+        }
+    std::vector<int32_t> new_index(size_t(n), -1);
+    for (size_t i = 0; i < top.size(); i++) new_index[size_t(top[i])] = int32_t(i);
+    int32_t at = int32_t(top.size());
+    for (int i = 0; i < n; i++) if (new_index[size_t(i)] < 0) new_index[size_t(i)] = at++;
+    std::vector<CwNode> moved(static_cast<size_t>(n));
+    parallel_pieces(n, [&](long long b, long long e) {
+        for (long long i = b; i < e; i++) {
+            CwNode nd = cw[size_t(i)];
+            for (int c = 0; c < 4; c++) if (nd.child[c] >= 0 && nd.child[c] < n) nd.child[c] = new_index[size_t(nd.child[c])];
+            moved[size_t(new_index[size_t(i)])] = nd;
+        }
+    });
+    cw.swap(moved);
+}
+
 // binned-SAH binary tree over the boxes, collapsed to compressed 4-wide nodes whose walk needs at most budget0 stack entries
 static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int budget0, FastBvh& out)
 {
@@ -596,6 +626,7 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
         for (size_t i = 0; i < ctasks.size(); i++) need = std::max(need, (budget0 - ctasks[i].budget) + part_need[i]);   // pushes above the subtree + below
     }
     out.cw_stack_need = need;
+    cw_top_first(out.cw, kFastTopNodes);
     if (talk) {
         const auto t2 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "fast hierarchy (host): %d triangles, SAH build %.2f s, collapse %.2f s, %zu binary / %zu wide nodes, depth %d, stack need %d\n", t,

@@ -19,6 +19,7 @@ constexpr int kFastMaxDepth = MCPT_FAST_STACK;          // inner levels; bounds 
 // The trace engine exists in two shapes (wavefront.hip): a 27-entry stack leaves LDS and registers for 4 waves per SIMD, the 36-entry
 // one for 3.  Hierarchies are built for the deep stack; the short-stack engine hands a ray that would overflow to the one-lane walk.
 constexpr int kFastShortStack = 27;
+constexpr int kFastTopNodes = 256;        // nodes the builder puts first, top of the tree breadth first (the engines keep a prefix of them in LDS)
 constexpr int kFastMaxLeaf = 8;            // most triangles a leaf may hold (3 bits of the reference: count - 1)
 constexpr int kFastDefaultLeaf = 4;        // default leaf size (measured: 4 beats 1 and 2 on MI355X; inner steps cost more than leaf boxes)
 constexpr int32_t kFastEmpty = INT32_MIN;  // child reference of an absent child

@@ -100,6 +100,7 @@ struct mcpt_device {
     DNode* nodes = nullptr; DTri* tris = nullptr; DTriShade* shade = nullptr; DMaterial* materials = nullptr;
     DLight* lights = nullptr; DLightTri* light_tris = nullptr; double* light_cdf = nullptr; uint8_t* texels = nullptr;
     FastNode* fast_nodes = nullptr; DTri* fast_tris = nullptr; CwNode* cw_nodes = nullptr; DTriPre* fast_pre = nullptr;
+    size_t n_cw_nodes = 0;          // nodes in cw_nodes when the hierarchy was built on the device
     int trace_mode = MCPT_TRACE_FAST;
     int32_t* d_order = nullptr;            // leaf -> .obj face (device build keeps it for read-back)
     mcpt_bvh_info bi{};
@@ -655,6 +656,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         fb.scene_absmax = amax;
         if (n_top == 1) {                        // small scene: the GPU's tree is the whole tree
             d->cw_nodes = d_lower;
+            d->n_cw_nodes = size_t(n_cw);
             fb.max_depth = levels;
             fb.cw_stack_need = 3 * levels;       // three siblings pushed per level on the way down
         } else {
@@ -671,6 +673,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
             if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
             (void)hipFree(d_lower);
             if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("device build of the fast hierarchy: ") + hipGetErrorString(e));
+            d->n_cw_nodes = size_t(n_up) + size_t(n_cw);
             fb.max_depth = up.max_depth + levels;
             fb.cw_stack_need = up.cw_stack_need;             // includes the clusters' 3 * levels
         }
@@ -735,6 +738,12 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     // walk (deep stack), and on every scene measured none does (10 M triangles: 0 of 1.5e8 rays).  MCPT_SHORT_KERNEL=0: the deep-stack
     // engine at 3 waves per SIMD.
     S.fast.stack_limit = kFastShortStack;
+    {
+        // (any prefix of the node array may be mirrored; the host builder puts the top of the tree there)
+        const size_t n_cw_total = fast_on_device ? d->n_cw_nodes : fb_ro.cw.size();
+        S.fast.cached = int32_t(std::min<size_t>(n_cw_total, size_t(kFastTopNodes)));
+        if (const char* e = std::getenv("MCPT_NODE_CACHE")) { const int v = std::atoi(e); if (v >= 0 && v < S.fast.cached) S.fast.cached = v; }
+    }
     if (const char* e = std::getenv("MCPT_SHORT_KERNEL")) if (std::atoi(e) == 0) S.fast.stack_limit = kFastMaxDepth;
     S.fast.stack_cap = S.fast.stack_limit;
     if (const char* e = std::getenv("MCPT_TEST_STACK_CAP")) { const int v = std::atoi(e); if (v >= 4 && v < S.fast.stack_cap) S.fast.stack_cap = v; }
@@ -819,6 +828,11 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
         std::fprintf(stderr, "k_wf_trace: %llu rays, %.3f nodes, %.3f triangles visited, %.3f exact tests per ray (%.1f %% of the visited triangles survive the pre-test)\n",
                      c.trace_rays, per(c.trace_nodes, c.trace_rays), per(c.trace_tris, c.trace_rays), per(c.trace_exact, c.trace_rays), 100.0 * per(c.trace_exact, c.trace_tris));
         std::fprintf(stderr, "rays deferred to the exact walk by k_wf_trace: %llu of %llu\n", c.pad[12], c.trace_rays);
+#ifdef MCPT_POOL_DEBUG
+        for (int i = 0; i < 4; i++) std::fprintf(stderr, "pool class %d: %llu steps, %.1f lanes per step (%.1f could before the claim)\n", i, c.dbg[8 + i], c.dbg[8 + i] ? double(c.dbg[12 + i]) / c.dbg[8 + i] : 0.0, c.dbg[8 + i] ? double(c.dbg[16 + i]) / c.dbg[8 + i] : 0.0);
+        std::fprintf(stderr, "pool: %llu sleeps, %llu steps that claimed nothing\n", c.dbg[20], c.dbg[21]);
+        std::fprintf(stderr, "pool debug: %llu launches, %llu slots in all, %llu consumed in %llu refill steps, %llu rays among them, %llu started, %llu slots retired, %llu tickets\n", c.dbg[5], c.dbg[4], c.dbg[0], c.dbg[2], c.dbg[1], c.dbg[7], c.dbg[3], c.dbg[6]);
+#endif
         if (c.pad[20]) {
             std::fprintf(stderr, "PRE-TEST SELF-CHECK: %llu rejected triangles are candidates by the exact test\n", c.pad[20]);
             double g[24]; std::memcpy(g, c.dbg, sizeof g);

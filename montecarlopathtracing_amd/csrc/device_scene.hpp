@@ -77,7 +77,7 @@ struct DFast {
     int32_t enabled;           // 0: scene has coordinates outside [1e-150,1e150] -> reference-shaped walk only
     int32_t stack_limit;       // per-lane stack entries of the trace engine that walks it: picks the short-stack or the deep-stack kernels
     int32_t stack_cap;         // entries of that stack the engine may use (= stack_limit; tests shrink it to force the overflow hand-over)
-    int32_t pad;
+    int32_t cached;            // cw[0 .. cached) is the top of the tree (accel_build.cpp: cw_top_first): the engines mirror a prefix of it in LDS
 };
 
 struct alignas(16) DMaterial {

@@ -12,6 +12,7 @@
 #include "shade_common.hpp"
 #include "shade_path.hpp"
 #include "trace_persistent.hpp"
+#include "trace_pool.hpp"
 
 namespace mcpt {
 
@@ -45,7 +46,15 @@ struct ArrayRaySource {
     const double* rays; long long n;
     int32_t* leaf_out; double* t_out; double* p_out;     // leaf_out receives the LEAF index; k_finish_hits turns it into a face
     __device__ __forceinline__ long long total() const { return n; }
-    __device__ __forceinline__ bool fetch(long long q, Ray& r) const { r.o = ld3(rays + q * 6); r.d = ld3(rays + q * 6 + 3); return true; }
+    __device__ __forceinline__ bool fetch(long long q, Ray& r) const
+    {
+        r.o = ld3(rays + q * 6); r.d = ld3(rays + q * 6 + 3);
+#ifdef MCPT_DBG_INVALID        /* debugging builds: a pseudo-random quarter of the slots holds no ray */
+        return ((((unsigned int)q * 2654435761u) >> 7) & 3u) != 0u;
+#else
+        return true;
+#endif
+    }
     __device__ __forceinline__ void store(long long q, bool ok, const Hit& h) const
     {
         leaf_out[q] = ok ? h.leaf : -1;
@@ -81,6 +90,19 @@ __global__ void __launch_bounds__(256, WAVES) k_trace_persistent(DScene S, Src s
     LaneStats ls;
     Work w = {0, 0};
     trace_persistent(S, src, queue, slow_list, slow_cap, chunk, lds_stack + threadIdx.x, 256, lds_rays + (threadIdx.x >> 6) * (MCPT_RAYBUF_BYTES / 8), w, S.fast.stack_cap < STACK ? S.fast.stack_cap : STACK);
+    ls.nodes = w.nodes; ls.tris = w.tris;
+    { const unsigned long long tw = wave_sum(w.pre_wrong); if ((threadIdx.x & 63) == 0 && tw && ctr) atomicAdd(&ctr->pad[20], tw); }
+    flush_stats(ctr, ls);
+}
+
+template <class Src, int NW, int KT, int SCAP>
+__global__ void __launch_bounds__(NW * 64, 1) k_trace_pool(DScene S, Src src, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
+                                                          long long chunk, DCounters* ctr)
+{
+    __shared__ PoolLds<NW, KT, SCAP> L;
+    LaneStats ls;
+    Work w = {0, 0};
+    trace_pool<Src, NW, KT, SCAP>(S, src, queue, slow_list, slow_cap, chunk, L, w);
     ls.nodes = w.nodes; ls.tris = w.tris;
     { const unsigned long long tw = wave_sum(w.pre_wrong); if ((threadIdx.x & 63) == 0 && tw && ctr) atomicAdd(&ctr->pad[20], tw); }
     flush_stats(ctr, ls);
@@ -236,14 +258,21 @@ static inline unsigned blocks_for(long long n, int block) { return (unsigned)((n
 
 template <class Src>
 static void launch_persistent(const DScene& S, const Src& src, long long total, TraceQueue* queue, long long* slow_list, unsigned int slow_cap,
-                              DCounters* ctr, hipStream_t st, int grid, int grid_short)
+                              DCounters* ctr, hipStream_t st, int grid, int grid_short, const LaunchCfg& cfg)
 {
     const bool shallow = S.fast.stack_limit <= kFastShortStack;
     const int resident = shallow ? grid_short : grid;
     const long long blocks_needed = (total + 255) / 256;
     const int g = (int)(blocks_needed < resident ? blocks_needed : resident);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    if (shallow) hipLaunchKernelGGL((k_trace_persistent<Src, kFastShortStack, 4>), dim3(g), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, persistent_chunk(total, g), ctr);
+    if (cfg.trace_pool) {
+        const long long per_block = cfg.trace_block_rays * (MCPT_POOL_WAVES / 4);
+        const long long nb = (total + per_block - 1) / per_block;
+        const int gp = (int)(nb < cfg.cus ? nb : cfg.cus);
+        long long c = total / ((long long)gp * MCPT_POOL_WAVES * 4);
+        c = (c / 64) * 64; c = c < cfg.min_chunk ? cfg.min_chunk : (c > cfg.max_chunk ? cfg.max_chunk : c);
+        hipLaunchKernelGGL((k_trace_pool<Src, MCPT_POOL_WAVES, MCPT_POOL_KT, MCPT_POOL_STACK>), dim3(gp), dim3(MCPT_POOL_WAVES * 64), 0, st, S, src, queue, slow_list, slow_cap, c, ctr);
+    } else if (shallow) hipLaunchKernelGGL((k_trace_persistent<Src, kFastShortStack, 4>), dim3(g), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, persistent_chunk(total, g), ctr);
     else hipLaunchKernelGGL((k_trace_persistent<Src, MCPT_FAST_STACK, 3>), dim3(g), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, persistent_chunk(total, g), ctr);
     hipLaunchKernelGGL(k_trace_slow<Src>, dim3(256), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, ctr);
 }
@@ -267,7 +296,7 @@ void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long
         return;
     }
     ArrayRaySource src; src.rays = d_rays; src.n = n; src.leaf_out = d_face; src.t_out = d_t; src.p_out = d_p;
-    launch_persistent(S, src, n, queue, slow_list, slow_cap, ctr, st, cfg.array_grid, cfg.array_grid_short);
+    launch_persistent(S, src, n, queue, slow_list, slow_cap, ctr, st, cfg.array_grid, cfg.array_grid_short, cfg);
     hipLaunchKernelGGL(k_finish_hits, dim3(blocks_for(n, 256)), dim3(256), 0, st, S, n, d_face, d_p, d_pn, ctr);
 }
 void launch_pack_pixels(const double* d_frame, const int32_t* d_pixels, long long n_pixels, double* d_out, hipStream_t st)
@@ -294,7 +323,7 @@ void launch_primary_hits(const DScene& S, bool fast, const double* d_dirs, const
     }
     PrimaryRaySource src; src.dirs = d_dirs; src.pixels = d_pixels; src.n_pixels = n_pixels; src.hits = d_hits;
     src.eye[0] = S.cam.eye[0]; src.eye[1] = S.cam.eye[1]; src.eye[2] = S.cam.eye[2];
-    launch_persistent(S, src, n_pixels, queue, slow_list, slow_cap, ctr, st, cfg.primary_grid, cfg.primary_grid_short);
+    launch_persistent(S, src, n_pixels, queue, slow_list, slow_cap, ctr, st, cfg.primary_grid, cfg.primary_grid_short, cfg);
 }
 void launch_shade_samples(const DScene& S, unsigned long long seed, const double* d_dirs, const int32_t* d_pixels,
                           const PrimaryHit* d_hits, int first_slot, int n_slots, int spp, double* d_rad, DCounters* ctr, hipStream_t st)

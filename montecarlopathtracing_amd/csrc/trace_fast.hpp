@@ -237,10 +237,35 @@ struct CwHits { float key[4]; int ref[4]; };
 
 // One step on a compressed node: which children may contain a candidate, sorted by lower bound of entry distance
 // (absent / culled children get key = +inf, ref = EMPTY).
+__device__ __forceinline__ CwHits cw_step_words(const uint4& w0, const uint4& w1, const uint4& w2, const uint4& w3, const RayF& f, float limit_f);
 __device__ __forceinline__ CwHits cw_step(const CwNode* __restrict__ nd, const RayF& f, float limit_f)
 {
     const uint4* q = reinterpret_cast<const uint4*>(nd);
     const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+    return cw_step_words(w0, w1, w2, w3, f, limit_f);
+}
+
+// The top of the tree mirrored in LDS (the block copies nodes [0, n) there when it starts): nearly every ray steps on these nodes, and a
+// node fetch is four 16-byte gathers per lane through the vector memory path, which the walk keeps as busy as the ALUs.
+#ifndef MCPT_NODE_CACHE_N
+#define MCPT_NODE_CACHE_N 96         /* nodes of it the engines hold (6 KB per block) */
+#endif
+struct NodeCache { const uint4* lds; int n; };
+__device__ __forceinline__ void fill_node_cache(uint4* lds, const CwNode* __restrict__ nodes, int n)
+{
+    const uint4* g = reinterpret_cast<const uint4*>(nodes);
+    for (int i = threadIdx.x; i < n * 4; i += blockDim.x) lds[i] = g[i];
+    __syncthreads();
+}
+__device__ __forceinline__ CwHits cw_step(const CwNode* __restrict__ nodes, int cur, const NodeCache& nc, const RayF& f, float limit_f)
+{
+    uint4 w0, w1, w2, w3;
+    if (cur < nc.n) { const uint4* q = nc.lds + cur * 4; w0 = q[0]; w1 = q[1]; w2 = q[2]; w3 = q[3]; }
+    else { const uint4* q = reinterpret_cast<const uint4*>(nodes + cur); w0 = q[0]; w1 = q[1]; w2 = q[2]; w3 = q[3]; }
+    return cw_step_words(w0, w1, w2, w3, f, limit_f);
+}
+__device__ __forceinline__ CwHits cw_step_words(const uint4& w0, const uint4& w1, const uint4& w2, const uint4& w3, const RayF& f, float limit_f)
+{
     const float p[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
     const int e[3] = {(int)(signed char)(w0.w & 255u), (int)(signed char)((w0.w >> 8) & 255u), (int)(signed char)((w0.w >> 16) & 255u)};
     const unsigned qlo[3] = {w1.x, w1.y, w1.z}, qhi[3] = {w1.w, w2.x, w2.y};

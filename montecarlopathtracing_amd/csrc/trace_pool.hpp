@@ -1,0 +1,513 @@
+// Closest-hit engine with the rays of a workgroup resident in LDS ("pool" engine): the persistent engine of trace_persistent.hpp keeps
+// one ray per lane in registers and lets the wave vote for a phase, so a phase runs with the lanes that happen to wait for it (58 % of
+// the lanes on cornell-box, 26 % in the exact block).  Here a workgroup of MCPT_POOL_WAVES waves owns 64 x KT ray slots whose whole
+// state -- ray, culling constants, leader, traversal stack -- lives in LDS, and a wave step is stateless: the wave picks a class
+// (node step / leaf pre-test / exact triangle test / finish + refill), every lane claims one slot of that class, loads what the step
+// needs, runs it, writes back what changed and files the slot under its next class.
+//
+//   * Slot s = k * 64 + lane is only ever handled by lane `lane` (of any wave): every LDS access of a step is [field][k][lane], i.e.
+//     conflict free, and there is no queue between waves -- per lane one 64-bit LDS word holds the class sets as four 16-bit masks
+//     (bit k of class c: slot k * 64 + lane waits for a step of class c).  Claim = atomic AND that clears the bit (the caller owns the
+//     slot iff the bit was set in the value returned), filing = atomic OR.  A claimed slot is in no mask, so nothing else touches it.
+//     No wave ever waits for another one: no barrier after the start, no spinning on data (the only sleep is "nothing claimable now").
+//   * A lane has work in class c if any of its KT slots (not held by another wave) waits for c: with a few slots per class that is
+//     nearly always, which is where the lanes per instruction come from.
+//   * LDS ordering: the LDS unit executes a wave's instructions in order; state writes precede the OR that files the slot, the reads
+//     follow the AND that claimed it.
+//   * The traversal stack is short (MCPT_POOL_STACK entries): a ray that would overflow it goes to the deferred list (one-lane walk with
+//     the deep stack), like in the short-stack shape of the persistent engine.
+// The decisions are the persistent engine's, test for test (same cw_step, tri_pre_reject, tri_hit, ranking, own-box check at the end),
+// so results are bit-identical to it and to the reference-shaped walk.
+#pragma once
+#include "trace_persistent.hpp"
+
+namespace mcpt {
+
+#ifndef MCPT_POOL_WAVES
+#define MCPT_POOL_WAVES 16
+#endif
+#ifndef MCPT_POOL_KT
+#define MCPT_POOL_KT 13             /* ray slots per lane (<= 16: one 16-bit mask per class) */
+#endif
+#ifndef MCPT_POOL_STACK
+#define MCPT_POOL_STACK 16
+#endif
+// vote: the class with the largest weight x (lanes that can claim a slot of it) runs; ties go downstream (finish > exact > leaf > node)
+#ifndef MCPT_POOL_CLAIMS
+#define MCPT_POOL_CLAIMS 2             /* attempts of a lane to claim a slot in one step */
+#endif
+#ifndef MCPT_POOL_PREFETCH
+#define MCPT_POOL_PREFETCH 0
+#endif
+#ifndef MCPT_POOL_CACHE_N
+#define MCPT_POOL_CACHE_N 88         /* nodes of the top of the tree held in LDS */
+#endif
+#ifndef MCPT_POOL_STICKY
+#define MCPT_POOL_STICKY 0          /* a lane whose slot stays at a node keeps it for the wave's next node step (no filing, no claim) */
+#endif
+#ifndef MCPT_POOL_PREF
+#define MCPT_POOL_PREF 0            /* > 0: every wave has a class it prefers (its score counts (4 + PREF) / 4): simultaneous voters spread out */
+#endif
+#ifndef MCPT_PW_INNER
+#define MCPT_PW_INNER 4
+#endif
+#ifndef MCPT_PW_LEAF
+#define MCPT_PW_LEAF 4
+#endif
+#ifndef MCPT_PW_EXACT
+#define MCPT_PW_EXACT 4
+#endif
+#ifndef MCPT_PW_FIN
+#define MCPT_PW_FIN 4
+#endif
+
+struct alignas(16) PoolOxy { double ox, oy; };
+struct alignas(16) PoolOzDx { double oz, dx; };
+struct alignas(16) PoolDyz { double dy, dz; };
+struct alignas(16) PoolRcp { float rx, ry, rz, px; };       // 1/d as floats, first pad of make_rayf
+struct alignas(8) PoolPyz { float py, pz; };
+struct alignas(16) PoolBest { double best_t, best_px; };
+
+// Every array is [k][lane] (a 16-byte group per lane where a step wants the words together, else one word per lane): consecutive lanes
+// touch consecutive banks whatever their k, so no access of a step has a bank conflict.  (Single words inside 16-byte groups were
+// 4-way conflicts: measured, a third of the LDS cycles.)
+template <int NW, int KT, int SCAP>
+struct PoolLds {
+    PoolOxy oxy[KT * 64];
+    PoolOzDx ozdx[KT * 64];
+    PoolDyz dyz[KT * 64];
+    PoolRcp rcp[KT * 64];
+    PoolBest best[KT * 64];
+    PoolPyz pyz[KT * 64];
+    long long q[KT * 64];                   // the ray's slot in the source
+    float limit[KT * 64], margin[KT * 64];
+    int cur[KT * 64];                       // node to step on / first triangle slot of the leaf
+    int tri_m[KT * 64];                     // leaf: number of triangles; exact class: mask of the survivors
+    int best_leaf[KT * 64];
+    int spf[KT * 64];                       // stack entries (bits 0-7) | flags
+    int stack[SCAP * KT * 64];              // [entry][k][lane]
+    unsigned long long mask[64];            // [lane]: class c in bits 16c .. 16c+15
+    int tbl[NW * 64];                       // refill: rank among the fetched rays -> lane that holds it
+    uint4 nodes[MCPT_POOL_CACHE_N * 4];     // the top of the tree (trace_fast.hpp: NodeCache)
+    unsigned int live;                      // slots that may still carry a ray
+    unsigned int dry;                       // waves whose supply of source slots has run out
+};
+
+// values that are the same in every lane, told to the compiler (scalar registers, scalar branches)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni(long long v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)v);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+
+template <class Src, int NW, int KT, int SCAP>
+__device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, TraceQueue* queue, long long* __restrict__ slow_list,
+                                           unsigned int slow_cap, long long chunk, PoolLds<NW, KT, SCAP>& L, Work& w)
+{
+    static_assert(KT <= 16, "one 16-bit mask per class");
+    enum { C_INNER = 0, C_LEAF = 1, C_EXACT = 2, C_FIN = 3, C_DEAD = 4 };
+    enum { F_FOUND = 256, F_AMBIG = 512, F_RAY = 1024 };
+    const DFast& F = S.fast;
+    const CwNode* __restrict__ nodes = F.cw;
+    const DTri* __restrict__ tris = F.tris;
+    const DTriPre* __restrict__ pre = F.pre;
+    const long long total = src.total();
+    const long long small = chunk < MCPT_TAIL_CHUNK ? chunk : MCPT_TAIL_CHUNK;
+    const long long big_tickets = (total - total / 8) / chunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int stack_cap = F.stack_cap < SCAP ? F.stack_cap : SCAP;
+
+    // every slot starts in the finish class without a ray: the first steps of every wave are refills
+    for (int k = wave; k < KT; k += NW) L.spf[k * 64 + lane] = 0;
+    const NodeCache ncache = {L.nodes, F.cached < MCPT_POOL_CACHE_N ? F.cached : MCPT_POOL_CACHE_N};
+    { const uint4* g = reinterpret_cast<const uint4*>(nodes); for (int i = threadIdx.x; i < ncache.n * 4; i += NW * 64) L.nodes[i] = g[i]; }
+    if (wave == 0) L.mask[lane] = (unsigned long long)((1u << KT) - 1u) << (16 * C_FIN);
+    if (threadIdx.x == 0) { L.live = KT * 64; L.dry = 0; }
+    __syncthreads();
+
+    unsigned int c_nodes = 0, c_rays = 0, c_exact = 0;
+#ifdef MCPT_POOL_DEBUG
+    unsigned long long d_used = 0, d_okc = 0, d_steps = 0, d_kill = 0, d_tickets = 0;
+    unsigned long long d_cs[4] = {0, 0, 0, 0}, d_cl[4] = {0, 0, 0, 0}, d_sleep = 0, d_miss = 0, d_want[4] = {0, 0, 0, 0};
+#endif
+    long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk of source slots
+    bool queue_empty = false;
+    int rot = wave % KT;                        // where a lane starts to look for a set bit: rotates, so no slot waits forever
+    bool keep = false;                          // MCPT_POOL_STICKY: this lane still owns slot keep_k, which waits for a node step
+    int keep_k = 0;
+#if MCPT_POOL_PREF
+    // nine waves of sixteen lean to the node step, three to the pre-test, two each to the exact test and the refill (their shares of the steps)
+    const int pref_slot = (wave * 16 / NW) & 15;
+    const int pref = pref_slot < 9 ? C_INNER : (pref_slot < 12 ? C_LEAF : (pref_slot < 14 ? C_EXACT : C_FIN));
+#endif
+
+    // What the slot's next step will read from memory is requested now -- by whichever wave runs that step, from the CU's L1 instead of
+    // from L2.  The loaded word is not looked at; it is folded into `junk` behind a later load of this wave (loads return in order), so
+    // nothing ever waits for it.
+    unsigned int pf = 0, junk = 0;
+#if MCPT_POOL_PREFETCH
+#define MCPT_TOUCH(ptr) pf += *reinterpret_cast<const volatile unsigned int*>(ptr)
+#else
+#define MCPT_TOUCH(ptr)
+#endif
+    auto touch_next = [&](bool node, int first, int cnt) __attribute__((always_inline)) {
+#if MCPT_POOL_PREFETCH
+        if (node) MCPT_TOUCH(nodes + first);
+        else if (pre) { MCPT_TOUCH(pre + first); if (cnt > 2) MCPT_TOUCH(pre + first + cnt - 1); }
+#endif
+    };
+
+    // the top of the slot's stack becomes its work (cur, tri_m, spf are written); returns the class it waits for
+    auto pop_next = [&](int idx, int k, int spf) __attribute__((always_inline)) -> int {
+        int sp = spf & 255;
+        if (sp == 0) return C_FIN;
+        sp--;
+        const int nxt = L.stack[(sp * KT + k) * 64 + lane];
+        const bool node = nxt >= 0;
+        const int ref = -1 - nxt;
+        const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
+        touch_next(node, first, cnt);
+        L.cur[idx] = first;
+        if (!node) L.tri_m[idx] = cnt;
+        L.spf[idx] = (spf & ~255) | sp;
+        return node ? C_INNER : C_LEAF;
+    };
+
+    for (;;) {
+        const unsigned long long m = __hip_atomic_load(&L.mask[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int n_inner = __popcll(__ballot(keep || (m & 0xffffull) != 0));
+        const int n_leaf = __popcll(__ballot((m & 0xffff0000ull) != 0));
+        const int n_exact = __popcll(__ballot((m & 0xffff00000000ull) != 0));
+        // A wave's claim on source slots is private (a chunk per ticket): once the tickets are gone, a wave without a chunk leaves the
+        // finish class to the waves that still have rays to hand out; a slot is retired only when every wave of the block is dry.
+        const bool fin_ok = !queue_empty || uni((int)__hip_atomic_load(&L.dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == NW;
+        const int n_fin = fin_ok ? __popcll(__ballot((m >> 48) != 0)) : 0;
+        if (!(n_inner | n_leaf | n_exact | n_fin)) {
+            // (no lane keeps a slot here: n_inner counts them)
+            if (uni((int)__hip_atomic_load(&L.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) break;
+            __builtin_amdgcn_s_sleep(4);         // the other waves hold what is left
+#ifdef MCPT_POOL_DEBUG
+            d_sleep++;
+#endif
+            continue;
+        }
+        int c = C_FIN, best_score = MCPT_PW_FIN * n_fin;
+        if (MCPT_PW_EXACT * n_exact > best_score) { c = C_EXACT; best_score = MCPT_PW_EXACT * n_exact; }
+        if (MCPT_PW_LEAF * n_leaf > best_score) { c = C_LEAF; best_score = MCPT_PW_LEAF * n_leaf; }
+        if (MCPT_PW_INNER * n_inner > best_score) { c = C_INNER; best_score = MCPT_PW_INNER * n_inner; }
+#if MCPT_POOL_PREF
+        {
+            const int s0 = MCPT_PW_INNER * n_inner * (pref == C_INNER ? 4 + MCPT_POOL_PREF : 4), s1 = MCPT_PW_LEAF * n_leaf * (pref == C_LEAF ? 4 + MCPT_POOL_PREF : 4);
+            const int s2 = MCPT_PW_EXACT * n_exact * (pref == C_EXACT ? 4 + MCPT_POOL_PREF : 4), s3 = MCPT_PW_FIN * n_fin * (pref == C_FIN ? 4 + MCPT_POOL_PREF : 4);
+            c = C_FIN; best_score = s3;
+            if (s2 > best_score) { c = C_EXACT; best_score = s2; }
+            if (s1 > best_score) { c = C_LEAF; best_score = s1; }
+            if (s0 > best_score) { c = C_INNER; best_score = s0; }
+        }
+#endif
+        c = uni(c);
+        // slots kept for a node step that is not the next step after all are filed now
+        if (c != C_INNER && __ballot(keep)) {
+            if (keep) __hip_atomic_fetch_or(&L.mask[lane], 1ull << (16 * C_INNER + keep_k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            keep = false;
+        }
+
+        // Claim: another wave's lane of the same index may be after the same slot (it read the same mask a moment ago).  Odd waves look
+        // from the top, even ones from the bottom, and a lane that lost tries once more on what the atomic returned (the fresh mask).
+        bool have = keep;
+        int k = keep_k;
+        keep = false;
+        unsigned long long cm = m;
+#pragma unroll
+        for (int attempt = 0; attempt < MCPT_POOL_CLAIMS; attempt++) {
+            const unsigned int mc = (unsigned int)(cm >> (16 * c)) & 0xffffu;
+            const bool want = !have && mc != 0u;
+            if (attempt && !__ballot(want)) break;
+            if (want) {
+                int kk;
+                if (wave & 1) { const unsigned int lo = mc & (0xffffu >> (15 - rot)); kk = 31 - __clz((int)(lo ? lo : mc)); }
+                else { const unsigned int hi = mc & (0xffffu << rot); kk = __ffs((int)(hi ? hi : mc)) - 1; }
+                const unsigned long long bit = 1ull << (16 * c + kk);
+                const unsigned long long old = __hip_atomic_fetch_and(&L.mask[lane], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                have = (old & bit) != 0ull;
+                k = kk;
+                cm = old & ~bit;
+            }
+        }
+        rot = rot + 1 == KT ? 0 : rot + 1;
+        const unsigned long long hv = __ballot(have);
+#ifdef MCPT_POOL_DEBUG
+        if (!hv) d_miss++;
+#endif
+        if (!hv) continue;
+        const int n_have = __popcll(hv);
+#ifdef MCPT_POOL_DEBUG
+        d_cs[c]++; d_cl[c] += n_have; d_want[c] += c == C_INNER ? n_inner : (c == C_LEAF ? n_leaf : (c == C_EXACT ? n_exact : n_fin));
+#endif
+        const int idx = k * 64 + lane;
+        int nc = C_DEAD;
+        __asm__ volatile("" ::: "memory");
+
+        if (c == C_INNER) {
+            // ---------------------------------------------------------------- one step on a compressed node
+            bool refused = false;
+            if (have) {
+                const int cur = L.cur[idx];
+                const int spf = L.spf[idx];
+                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolRcp a4 = L.rcp[idx]; const PoolPyz a5 = L.pyz[idx];
+                const float limit = L.limit[idx];
+                int sp = spf & 255;
+                if (sp > stack_cap - 3) {        // three pushes must fit: the ray goes to the one-lane walk
+                    L.spf[idx] = spf | F_AMBIG; nc = C_FIN; refused = true;
+                } else {
+                    RayF rf;
+                    rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
+                    rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
+                    rf.pad[0] = a4.px; rf.pad[1] = a5.py; rf.pad[2] = a5.pz;
+                    const CwHits h = cw_step(nodes, cur, ncache, rf, limit);
+                    junk += pf; pf = 0;
+                    if (h.ref[3] != MCPT_FAST_EMPTY) { L.stack[(sp * KT + k) * 64 + lane] = h.ref[3]; sp++; }
+                    if (h.ref[2] != MCPT_FAST_EMPTY) { L.stack[(sp * KT + k) * 64 + lane] = h.ref[2]; sp++; }
+                    if (h.ref[1] != MCPT_FAST_EMPTY) { L.stack[(sp * KT + k) * 64 + lane] = h.ref[1]; sp++; }
+                    int nxt = h.ref[0];
+                    if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = L.stack[(sp * KT + k) * 64 + lane]; }
+                    const bool node = nxt >= 0, none = nxt == MCPT_FAST_EMPTY;
+                    const int ref = -1 - nxt;
+                    const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
+                    if (!none) { touch_next(node, first, cnt); L.cur[idx] = first; }
+                    if (!node && !none) L.tri_m[idx] = cnt;
+                    L.spf[idx] = (spf & ~255) | sp;
+                    nc = node ? C_INNER : (none ? C_FIN : C_LEAF);
+                }
+            }
+            c_nodes += (unsigned int)(n_have - __popcll(__ballot(refused)));
+        } else if (c == C_LEAF) {
+            // ---------------------------------------------------------------- the triangles of a leaf through the fp32 pre-test
+            if (have) {
+                const int cur = L.cur[idx];
+                const int cnt = L.tri_m[idx];
+                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
+                const float limit = L.limit[idx], margin = L.margin[idx];
+                unsigned int surv = 0;
+                w.tris += cnt;
+#if MCPT_PRE_TEST
+                if (!pre) surv = (1u << cnt) - 1u;
+                else {
+                    Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
+                    const float of[3] = {(float)a0.ox, (float)a0.oy, (float)a1.oz};
+                    const PreRay pr = make_pre_ray(F, r, of, margin);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                    for (int k0 = 0; k0 < cnt; k0 += MCPT_PRE_UNROLL) {
+#pragma unroll
+                        for (int j = 0; j < MCPT_PRE_UNROLL; j++) {
+                            const int kk = k0 + j;
+                            const bool rej = tri_pre_reject(pre + cur + kk, pr, limit);
+                            if (kk < cnt && !rej) surv |= 1u << kk;
+                        }
+                    }
+                    junk += pf; pf = 0;
+#ifdef MCPT_PRE_CHECK
+                    const PoolBest a6 = L.best[idx];
+                    const bool found = (L.spf[idx] & F_FOUND) != 0;
+                    for (int kk = 0; kk < cnt; kk++) {
+                        if ((surv >> kk) & 1u) continue;
+                        V3 pc;
+                        if (tri_hit(tris + cur + kk, r, pc)) {
+                            const double tc = (pc.x - r.o.x) / r.d.x;
+                            if (tc > 0.0 && (!found || tc <= a6.best_t * (1.0 + 0x1p-40))) { w.pre_wrong++; surv |= 1u << kk; }
+                        }
+                    }
+#endif
+                }
+#else
+                surv = (1u << cnt) - 1u;
+#endif
+                if (surv) {
+#if MCPT_POOL_PREFETCH
+                    { const DTri* tn = tris + cur + (__ffs((int)surv) - 1); MCPT_TOUCH(tn); MCPT_TOUCH(reinterpret_cast<const char*>(tn) + 64); }
+#endif
+                    L.tri_m[idx] = (int)surv; nc = C_EXACT;
+                }
+                else nc = pop_next(idx, k, L.spf[idx]);
+            }
+        } else if (c == C_EXACT) {
+            // ---------------------------------------------------------------- one surviving triangle through the reference's test
+            c_exact += (unsigned int)n_have;
+            if (have) {
+                const int cur = L.cur[idx];
+                int surv = L.tri_m[idx];
+                int spf = L.spf[idx];
+                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
+                const PoolBest a6 = L.best[idx];
+                Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
+                const int kk = __ffs(surv) - 1;
+                surv &= surv - 1;
+                const int ti = cur + kk;
+                const DTri* tr = tris + ti;
+                const bool found = (spf & F_FOUND) != 0;
+                V3 p;
+                const bool hit = tri_hit(tr, r, p);
+                junk += pf; pf = 0;
+                if (hit) {
+                    const double ta = (p.x - r.o.x) * fast_rcp(r.d.x);
+                    if (ta > 0.0) {
+                        const double band = a6.best_t * 0x1p-47;
+                        if (!found || ta < a6.best_t - band) {
+                            PoolBest nb; nb.best_t = ta; nb.best_px = p.x;
+                            L.best[idx] = nb; L.best_leaf[idx] = ti;
+                            L.limit[idx] = __double2float_ru((ta + ta * 0x1p-47) + (double)L.margin[idx]);
+                            spf |= F_FOUND;
+                        } else if (!(ta > a6.best_t + band)) {
+                            const double t_new = (p.x - r.o.x) / r.d.x, t_old = (a6.best_px - r.o.x) / r.d.x;
+                            if (t_new < t_old || (t_new == t_old && tr->leaf < tris[L.best_leaf[idx]].leaf)) {
+                                PoolBest nb; nb.best_t = ta; nb.best_px = p.x;
+                                L.best[idx] = nb; L.best_leaf[idx] = ti;
+                            }
+                        }
+                    }
+                }
+                if (surv) {
+#if MCPT_POOL_PREFETCH
+                    { const DTri* tn = tris + cur + (__ffs(surv) - 1); MCPT_TOUCH(tn); MCPT_TOUCH(reinterpret_cast<const char*>(tn) + 64); }
+#endif
+                    L.tri_m[idx] = surv; L.spf[idx] = spf; nc = C_EXACT;
+                }
+                else nc = pop_next(idx, k, spf);
+                if (nc == C_FIN) L.spf[idx] = spf;
+            }
+        } else {
+            // ---------------------------------------------------------------- results out, new rays in
+            if (have) {
+                const int spf = L.spf[idx];
+                if (spf & F_RAY) {
+                    const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
+                    const PoolBest a6 = L.best[idx];
+                    const long long slot = L.q[idx];
+                    Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
+                    const bool found = (spf & F_FOUND) != 0;
+                    bool ambiguous = (spf & F_AMBIG) != 0;
+                    Hit h; h.leaf = -1; h.t = 0; h.p = mk(0, 0, 0);
+                    if (found) {
+                        const V3 rc = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+                        const DTri* tr = tris + L.best_leaf[idx];
+                        if (!own_box_hit(tr, r, rc)) ambiguous = true;
+                        h.leaf = tr->leaf;
+                        h.mat = tr->material;
+                        h.t = (a6.best_px - r.o.x) / r.d.x;
+                        if constexpr (Src::kWantsPoint) {
+                            const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
+                            const double t = dot(v1 - r.o, n) / dot(n, r.d);
+                            h.p = r.o + r.d * t;
+                        }
+                    }
+                    if (ambiguous) {
+                        const unsigned int at = atomicAdd(&queue->slow_count, 1u);
+                        if (at < slow_cap) slow_list[at] = slot;
+                        else queue->redo_all = 1u;
+                    } else src.store(slot, found, h);
+                }
+            }
+            bool got = false;
+            bool all_dry = queue_empty;             // (a dry wave is only here when every wave is)
+            if (!queue_empty && next >= range_end) {
+                unsigned long long tk = 0;
+                if (lane == 0) tk = atomicAdd(&queue->head, 1ull);
+                const long long ticket = uni((long long)tk);
+                const long long size = ticket < big_tickets ? chunk : small;
+                next = ticket < big_tickets ? ticket * chunk : big_tickets * chunk + (ticket - big_tickets) * small;
+                range_end = next + size < total ? next + size : total;
+#ifdef MCPT_POOL_DEBUG
+                d_tickets++;
+#endif
+                if (next >= total) {
+                    queue_empty = true;
+                    unsigned int before = 0;
+                    if (lane == 0) before = __hip_atomic_fetch_add(&L.dry, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    all_dry = uni((int)before) + 1 == NW;
+                }
+            }
+            if (!queue_empty) {
+                // the next <= 64 source slots, one per lane; the rays among them go to the lanes that need one, in order
+                const long long left = range_end - next;
+                const int avail = left < 64 ? (int)left : 64;
+                Ray nr; nr.o = mk(0, 0, 0); nr.d = mk(1, 1, 1);
+                const bool valid = lane < avail && src.fetch(next + lane, nr);
+                const bool ok = valid && fast_path_ok(F, nr);
+                junk += pf; pf = 0;
+                const unsigned long long V = __ballot(ok);
+                const int n_ok = __popcll(V);
+                const int rank_ok = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(V >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)V, 0u));
+                int used = avail;                // source slots consumed by this step
+                if (n_ok > n_have) used = __ffsll((long long)__ballot(ok && rank_ok == n_have - 1));
+                used = uni(used);
+                if (valid && !ok && lane < used) {      // a ray the fast walk may not take
+                    const unsigned int at = atomicAdd(&queue->slow_count, 1u);
+                    if (at < slow_cap) slow_list[at] = next + lane;
+                }
+                if (ok && rank_ok < n_have) L.tbl[wave * 64 + rank_ok] = lane;
+                const int rank_need = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(hv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)hv, 0u));
+                got = have && rank_need < n_ok;
+                __asm__ volatile("" ::: "memory");
+                const int from = got ? L.tbl[wave * 64 + rank_need] : lane;
+                Ray r;
+                r.o.x = __shfl(nr.o.x, from, 64); r.o.y = __shfl(nr.o.y, from, 64); r.o.z = __shfl(nr.o.z, from, 64);
+                r.d.x = __shfl(nr.d.x, from, 64); r.d.y = __shfl(nr.d.y, from, 64); r.d.z = __shfl(nr.d.z, from, 64);
+                if (got) {
+                    const V3 rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+                    const double rmax = fmax(fmax(fabs(rcp.x), fabs(rcp.y)), fabs(rcp.z));
+                    const double scale = fmax(fmax(F.absmax, fabs(r.o.x)), fmax(fabs(r.o.y), fabs(r.o.z)));
+                    const RayF rf = make_rayf(F, r, rcp);
+                    PoolOxy b0; b0.ox = r.o.x; b0.oy = r.o.y;
+                    PoolOzDx b1; b1.oz = r.o.z; b1.dx = r.d.x;
+                    PoolDyz b2; b2.dy = r.d.y; b2.dz = r.d.z;
+                    PoolRcp b4; b4.rx = rf.r[0]; b4.ry = rf.r[1]; b4.rz = rf.r[2]; b4.px = rf.pad[0];
+                    PoolPyz b5; b5.py = rf.pad[1]; b5.pz = rf.pad[2];
+                    PoolBest b6; b6.best_t = 0; b6.best_px = 0;
+                    L.oxy[idx] = b0; L.ozdx[idx] = b1; L.dyz[idx] = b2; L.rcp[idx] = b4; L.pyz[idx] = b5; L.best[idx] = b6;
+                    L.limit[idx] = __builtin_inff();
+                    L.margin[idx] = rmax <= 1e6 ? __double2float_ru(1.0000001e-9 * scale * rmax) : __builtin_inff();
+                    L.cur[idx] = 0; L.tri_m[idx] = 0; L.best_leaf[idx] = -1; L.spf[idx] = F_RAY;
+                    L.q[idx] = next + from;
+                    MCPT_TOUCH(nodes);
+                    nc = C_INNER;
+                }
+                next += used;
+#ifdef MCPT_POOL_DEBUG
+                d_used += used; d_okc += __popcll(__ballot(ok && lane < used)); d_steps++;
+#endif
+                c_rays += (unsigned int)__popcll(__ballot(got));
+            }
+            if (have && !got) {
+                if (queue_empty && all_dry) nc = C_DEAD;           // no ray left for this slot, in any wave
+                else { L.spf[idx] = 0; nc = C_FIN; }               // it asks again
+            }
+            const int n_dead = __popcll(__ballot(have && nc == C_DEAD));
+#ifdef MCPT_POOL_DEBUG
+            d_kill += n_dead;
+#endif
+            if (n_dead && lane == 0) __hip_atomic_fetch_sub(&L.live, (unsigned int)n_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __asm__ volatile("" ::: "memory");
+#if MCPT_POOL_STICKY
+        if (have && c == C_INNER && nc == C_INNER) { keep = true; keep_k = k; nc = C_DEAD; }      // (not filed: it stays with this lane)
+#endif
+        if (have && nc != C_DEAD)
+            __hip_atomic_fetch_or(&L.mask[lane], 1ull << (16 * nc + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#undef MCPT_TOUCH
+    junk += pf;
+    if (lane == 0) { w.nodes += c_nodes + (junk == 0x9e3779b9u ? 1u : 0u); w.rays += c_rays; w.exact += c_exact; }
+#ifdef MCPT_POOL_DEBUG
+    if (lane == 0 && w.dbg) {
+        atomicAdd(&w.dbg[0], d_used); atomicAdd(&w.dbg[1], d_okc); atomicAdd(&w.dbg[2], d_steps); atomicAdd(&w.dbg[3], d_kill); atomicAdd(&w.dbg[6], d_tickets);
+        atomicAdd(&w.dbg[7], (unsigned long long)c_rays);
+        for (int i = 0; i < 4; i++) { atomicAdd(&w.dbg[8 + i], d_cs[i]); atomicAdd(&w.dbg[12 + i], d_cl[i]); atomicAdd(&w.dbg[16 + i], d_want[i]); }
+        atomicAdd(&w.dbg[20], d_sleep); atomicAdd(&w.dbg[21], d_miss);
+        if (threadIdx.x == 0 && blockIdx.x == 0) { atomicAdd(&w.dbg[4], (unsigned long long)total); atomicAdd(&w.dbg[5], 1ull); }
+    }
+#endif
+}
+
+}  // namespace mcpt

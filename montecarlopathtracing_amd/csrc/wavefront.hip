@@ -1,12 +1,15 @@
 // Wavefront integrator kernels (see wavefront.hpp).  -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "accel_build.hpp"
 #include "dev_common.hpp"
 #include "shade_common.hpp"
 #include "trace_persistent.hpp"
+#include "trace_pool.hpp"
 #include "vertex.hpp"
 #include "wavefront.hpp"
 
@@ -297,7 +300,7 @@ struct WfRaySource {
 // persistent fast walk
 __device__ __forceinline__ long long wf_chunk(long long total, int min_chunk, int max_chunk)
 {
-    const long long waves = (long long)gridDim.x * 4;
+    const long long waves = (long long)gridDim.x * (blockDim.x >> 6);
     long long c = total / (waves * 4);
     c = (c / 64) * 64;
     return c < min_chunk ? min_chunk : (c > max_chunk ? max_chunk : c);
@@ -332,6 +335,33 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_trace(DScene S, WfArgs a, Tra
 #ifdef MCPT_TRACE_DIAG
     if ((threadIdx.x & 63) == 0 && a.ctr) for (int i = 0; i < 12; i++) atomicAdd(&a.ctr->pad[i], w.diag[i]);
 #endif
+    flush_stats(a.ctr, ls);
+}
+
+// The pool engine (trace_pool.hpp): one workgroup per CU, its rays resident in LDS.
+template <int NW, int KT, int SCAP>
+__global__ void __launch_bounds__(NW * 64, 1) k_wf_trace_pool(DScene S, WfArgs a, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, int min_chunk, int max_chunk)
+{
+    const long long n_paths = a.counts->n_next;
+    if (n_paths <= (long long)a.finish_below) return;
+    const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk, max_chunk);
+    __shared__ PoolLds<NW, KT, SCAP> L;
+    WfRaySource src; src.a = a; src.n_paths = n_paths;
+    LaneStats ls;
+    Work w = {0, 0};
+#ifdef MCPT_POOL_DEBUG
+    if (a.ctr) w.dbg = a.ctr->dbg;
+#endif
+    trace_pool<WfRaySource, NW, KT, SCAP>(S, src, queue, slow_list, slow_cap, chunk, L, w);
+    ls.nodes = w.nodes; ls.tris = w.tris;
+    if (a.ctr) {
+        const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays), te = wave_sum(w.exact);
+        if ((threadIdx.x & 63) == 0 && (tn | tt | tr | te)) {
+            atomicAdd(&a.ctr->trace_nodes, tn); atomicAdd(&a.ctr->trace_tris, tt); atomicAdd(&a.ctr->trace_rays, tr); atomicAdd(&a.ctr->trace_exact, te);
+        }
+        const unsigned long long tw = wave_sum(w.pre_wrong);
+        if ((threadIdx.x & 63) == 0 && tw) atomicAdd(&a.ctr->pad[20], tw);
+    }
     flush_stats(a.ctr, ls);
 }
 
@@ -691,6 +721,8 @@ void init_launch_cfg(LaunchCfg& cfg)
     c = e ? std::atoi(e) : 0;
     cfg.max_chunk = c >= 64 ? c / 64 * 64 : 2048;
     if (cfg.max_chunk < cfg.min_chunk) cfg.max_chunk = cfg.min_chunk;
+    e = std::getenv("MCPT_TRACE_ENGINE");
+    cfg.trace_pool = (e && std::strcmp(e, "pool") == 0) ? 1 : 0;
     init_launch_cfg_closest(cfg);
 }
 
@@ -718,7 +750,13 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
     const long long blocks_needed = (total + cfg.trace_block_rays - 1) / cfg.trace_block_rays;
     const int g = (int)(blocks_needed < resident ? blocks_needed : resident);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    if (shallow) hipLaunchKernelGGL((k_wf_trace<kFastShortStack, 4>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
+    if (cfg.trace_pool) {
+        const long long per_block = cfg.trace_block_rays * (MCPT_POOL_WAVES / 4);
+        const long long nb = (total + per_block - 1) / per_block;
+        const int gp = (int)(nb < cfg.cus ? nb : cfg.cus);
+        hipLaunchKernelGGL((k_wf_trace_pool<MCPT_POOL_WAVES, MCPT_POOL_KT, MCPT_POOL_STACK>), dim3(gp), dim3(MCPT_POOL_WAVES * 64), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
+        { const hipError_t le = hipGetLastError(); if (le != hipSuccess) std::fprintf(stderr, "k_wf_trace_pool launch: %s\n", hipGetErrorString(le)); }
+    } else if (shallow) hipLaunchKernelGGL((k_wf_trace<kFastShortStack, 4>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
     else hipLaunchKernelGGL((k_wf_trace<MCPT_FAST_STACK, 3>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
     hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 512 ? g : 512), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);   // (blocks without work leave at once)
 }

@@ -278,6 +278,44 @@ def test_wavefront_iterations_against_megakernel_and_oracle(pair, oracle, mcpt, 
         dev.close()
 
 
+def test_pool_engine_equals_voting_engine(pair, mcpt, monkeypatch):
+    """MCPT_TRACE_ENGINE=pool selects the closest-hit engine whose rays live in LDS (csrc/trace_pool.hpp: stateless wave steps on slots
+    claimed with LDS atomics) for the primary rays, mcpt_trace_closest and every k_wf_trace launch.  Same tests on the same triangles:
+    face / t / p / pn of 300 k rays (camera, interior, adversarial, on-surface origins) and whole wavefront frames with the hand-over
+    to k_wf_finish switched off must equal the default engine's bit for bit, with the same work (nodes stepped on, triangles visited)."""
+    name, osc, sc, dev0 = pair
+    base = make_rays(osc, 200000, seed=21)
+    f0, t0, p0, n0 = dev0.ray_intersect(base)
+    hit = f0 >= 0
+    rng = np.random.default_rng(8)
+    d = rng.normal(size=(int(hit.sum()), 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.vstack([base, np.hstack([p0[hit] + 0.01 * d, d])[:60000], np.hstack([p0[hit], d])[:40000]])
+    monkeypatch.setenv("MCPT_FINISH_PATHS", "0")
+    dv = mcpt.Device(sc, 0)
+    monkeypatch.setenv("MCPT_TRACE_ENGINE", "pool")
+    dp = mcpt.Device(sc, 0)
+    try:
+        sv, sp = mcpt.Stats(), mcpt.Stats()
+        rv = dv.ray_intersect(rays, stats=sv)
+        rp = dp.ray_intersect(rays, stats=sp)
+        assert np.array_equal(rv[0], rp[0]), "%d faces differ" % int((rv[0] != rp[0]).sum())
+        h = rv[0] >= 0
+        for a, b in zip(rv[1:], rp[1:]):
+            assert np.array_equal(_bits(a[h]), _bits(b[h]))
+        for spp in (1, 8):                  # (a tiny launch per bounce; then some tens of thousands of rays per launch)
+            a = dv.generateImg(spp, seed=5, stats=sv)
+            b = dp.generateImg(spp, seed=5, stats=sp)
+            assert np.array_equal(_bits(a), _bits(b)), "%d channels differ" % int((_bits(a) != _bits(b)).sum())
+            assert sv.dom_rays == sp.dom_rays
+            # (a ray whose walk needs more than the pool's 16 stack entries finishes in the one-lane walk, which counts elsewhere)
+            assert abs(sv.dom_node_visits - sp.dom_node_visits) <= 0.01 * sv.dom_node_visits and abs(sv.dom_tri_tests - sp.dom_tri_tests) <= 0.01 * sv.dom_tri_tests
+            assert sp.dom_rays > 0.9 * (sp.rays_shadow + sp.rays_bounce)
+    finally:
+        dv.close()
+        dp.close()
+
+
 def _gpu_emitter_map(mcpt, sc, dev):
     """[H, W] bool from the product's own frame: at SPP 1 a pixel whose primary hit is an emitter holds the light's radiance
     exactly -- rounded to float, the accumulator is a glm::vec3 (pathTracing.cpp:141-144, :301; k_primary_dirs -> primary hits
