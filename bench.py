@@ -152,7 +152,7 @@ def cpu_baseline(scene_dir, name, seed, target_seconds=15.0):
 
 def make_scene(M, args, local_rank=0, talk=True):
     """(scene, scene_dir or None, build mode for the device handles)"""
-    build_mode = {"default": None, "host": M.BUILD_HOST, "device": M.BUILD_DEVICE, "device_fast": M.BUILD_DEVICE_FAST}[args.build]
+    build_mode = {"default": None, "host": M.BUILD_HOST, "device": M.BUILD_DEVICE, "device_fast": M.BUILD_DEVICE_FAST, "device_sah": M.BUILD_DEVICE_SAH}[args.build]
     if args.scene == "synthetic":
         from montecarlopathtracing_amd import synthetic
         t_gen = time.perf_counter()
@@ -360,8 +360,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="size of the CPU baseline's bounded sample")
     ap.add_argument("--save-png", default=None)
     ap.add_argument("--tris", type=int, default=10_000_000, help="--scene synthetic: number of lattice triangles")
-    ap.add_argument("--build", default="default", choices=["default", "host", "device", "device_fast"],
-                    help="where the BVHs are built (mcpt_device_create_ex); device_fast: the fast walk's hierarchy on the GPU too")
+    ap.add_argument("--build", default="default", choices=["default", "host", "device", "device_fast", "device_sah"],
+                    help="where the BVHs are built (mcpt_device_create_ex); device_fast / device_sah: the fast walk's hierarchy on the GPU too (Morton clusters / locally-ordered clustering)")
     ap.add_argument("--pipeline", action="store_true", help="one GPU, diagnostic: two frames in flight on two streams (a step is then 1/throughput, not a latency)")
     ap.add_argument("--sim-world", type=int, default=0, help="one GPU, diagnostic: render only one rank's tiles of an N-rank partition")
     ap.add_argument("--sim-rank", type=int, default=0, help="with --sim-world: which rank's tiles")

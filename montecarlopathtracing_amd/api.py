@@ -13,7 +13,7 @@ RENDER_DEFAULT, RENDER_MEGAKERNEL = 0, 2
 RENDER_KEEP_STATS, RENDER_PIPELINE = 4, 8
 LOAD_STANDARD_OBJ, LOAD_MTLLIB, LOAD_MORTON_BOUNDS = 1, 2, 4
 OUT_PNG_DEFLATE, OUT_PFM = 1, 2
-BUILD_HOST, BUILD_DEVICE, BUILD_DEVICE_FAST = 0, 1, 2
+BUILD_HOST, BUILD_DEVICE, BUILD_DEVICE_FAST, BUILD_DEVICE_SAH = 0, 1, 2, 3
 SCENE_DEFER_BUILD = 1
 GATHER_PEER, GATHER_RCCL = 0, 1
 

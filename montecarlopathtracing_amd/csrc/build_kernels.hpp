@@ -30,6 +30,16 @@ hipError_t device_build_reference(const BuildInputs& in, const mcpt_bvh_info& bi
 // shape cannot change a result.  *cw and *fast_tris are hipMalloc'ed here; the walk needs 3 stack entries per level.
 hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], const double hi[3], int per_leaf, int max_levels, CwNode** cw, DTri** fast_tris,
                              int* n_nodes, int* levels, int* n_top, std::vector<double>* top_boxes, double* absmax, hipStream_t st);
+// MCPT_BUILD_DEVICE_SAH: the lower part grown on the device by parallel locally-ordered clustering into subtrees of at most max_cluster
+// triangles and max_height binary levels, each collapsed into compressed 4-wide nodes (leaves of up to max_leaf triangles where the
+// surface-area heuristic, evaluated bottom up with cost_leaf + cost_tri per triangle for a leaf and 1 for a node, prefers a leaf to a split).  Cluster c's
+// nodes are a run of *cw starting at top_roots[c] (its root; < 0: the cluster is one leaf and this is its reference); top_boxes as above;
+// hipErrorNotSupported: the clusters leave the tree above them too few of the walk's stack entries (take another builder); lower_need = stack entries a walk below a cluster
+// root can hold.  rounds = clustering rounds it took.
+hipError_t device_build_ploc(const DTri* leaf_tris, int t, const double lo[3], const double hi[3], int max_cluster, int max_height, int radius, int max_leaf,
+                             double area_fraction /* of the scene box's area a cluster's box may have; 0: no limit */, double cost_tri, double cost_leaf,
+                             int collapse_budget /* stack entries below a cluster root; 0: chosen from the number of clusters */, CwNode** cw, DTri** fast_tris, int* n_nodes, int* n_top, std::vector<double>* top_boxes, std::vector<int32_t>* top_roots,
+                             int* lower_need, double* absmax, int* rounds, hipStream_t st);
 hipError_t device_offset_children(CwNode* nodes, int n, int off, hipStream_t st);     // child >= 0 -> child + off
 hipError_t device_gather_tris(const DTri* tris, const int32_t* d_slots, int n, DTri* out, hipStream_t st);
 // the pre-test's fp32 record of every slot of the fast triangle array (absmax = largest |coordinate| of the scene)

@@ -489,7 +489,8 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
 {
     if (!h || !out) return fail(MCPT_ERR_ARG, "null argument");
     *out = nullptr;
-    if (build_mode != MCPT_BUILD_HOST && build_mode != MCPT_BUILD_DEVICE && build_mode != MCPT_BUILD_DEVICE_FAST) return fail(MCPT_ERR_ARG, "bad build mode");
+    if (build_mode != MCPT_BUILD_HOST && build_mode != MCPT_BUILD_DEVICE && build_mode != MCPT_BUILD_DEVICE_FAST && build_mode != MCPT_BUILD_DEVICE_SAH)
+        return fail(MCPT_ERR_ARG, "bad build mode");
     const Scene& s = h->s;
     if (build_mode == MCPT_BUILD_HOST && !s.accel_built) return fail(MCPT_ERR_ARG, "scene has no host build; use MCPT_BUILD_DEVICE");
     int ndev = mcpt_device_count();
@@ -514,7 +515,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         if (talk) std::fprintf(stderr, "device create: %s at %.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count());
     };
     std::vector<int32_t> order;                     // leaf -> .obj face
-    const bool fast_on_device = build_mode == MCPT_BUILD_DEVICE_FAST;
+    const bool fast_on_device = build_mode == MCPT_BUILD_DEVICE_FAST || build_mode == MCPT_BUILD_DEVICE_SAH;
     if (build_mode == MCPT_BUILD_HOST) {
         std::vector<DNode> nodes(bi.Nr);
         for (int i = 0; i < bi.Nr; i++) {
@@ -651,6 +652,64 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         CwNode* d_lower = nullptr;
         int n_top = 0;
         std::vector<double> top_boxes;
+        bool ploc_fell_back = false;
+        if (build_mode == MCPT_BUILD_DEVICE_SAH) {
+            // clusters grown by locally-ordered clustering on the GPU (build_kernels.hip: device_build_ploc), the host's SAH tree over them
+            static const int kCluster = [] { const char* e = std::getenv("MCPT_PLOC_CLUSTER"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 65536 ? v : 4096; }();
+            static const int kHeightEnv = [] { const char* e = std::getenv("MCPT_PLOC_HEIGHT"); const int v = e ? std::atoi(e) : 0; return v >= 3 && v <= 24 ? v : 0; }();
+            // how tall a cluster may grow: what the walk's stack leaves once the tree over the expected number of clusters has its levels
+            int kHeight = kHeightEnv;
+            if (!kHeight) {
+                const long long est = std::max<long long>(1, 2ll * t / kCluster);
+                int lv = 1;
+                while ((1ll << lv) < est) lv++;
+                kHeight = std::max(6, std::min(20, 35 - 5 - lv));
+            }
+            static const int kRadius = [] { const char* e = std::getenv("MCPT_PLOC_RADIUS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 64 ? v : 8; }();
+            static const double kAreaDen = [] { const char* e = std::getenv("MCPT_PLOC_AREA"); const double v = e ? std::atof(e) : 0; return v >= 0 && e ? v : 16.0; }();
+            static const double kCt = [] { const char* e = std::getenv("MCPT_PLOC_CT"); const double v = e ? std::atof(e) : 0; return v > 0 ? v : 1.0; }();
+            static const double kCl = [] { const char* e = std::getenv("MCPT_PLOC_CL"); return e ? std::atof(e) : 0.0; }();
+            static const int kLeaf = [] { const char* e = std::getenv("MCPT_PLOC_LEAF"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= kFastMaxLeaf ? v : kFastDefaultLeaf; }();
+            static const int kBudget = [] { const char* e = std::getenv("MCPT_PLOC_BUDGET"); const int v = e ? std::atoi(e) : 0; return v >= 3 && v <= 30 ? v : 0; }();
+            std::vector<int32_t> top_roots;
+            int lower_need = 0, rounds = 0;
+            hipError_t e = device_build_ploc(d->tris, t, blo, bhi, kCluster, kHeight, kRadius, kLeaf, kAreaDen > 0 ? 1.0 / kAreaDen : 0.0, kCt, kCl, kBudget, &d_lower, &d->fast_tris, &n_cw, &n_top, &top_boxes,
+                                             &top_roots, &lower_need, &amax, &rounds, d->stream);
+            if (e == hipErrorNotSupported) ploc_fell_back = true;
+            else {
+            if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("device build of the fast hierarchy (clustering): ") + hipGetErrorString(e));
+            lap("clusters on the GPU");
+            if (talk) std::fprintf(stderr, "device create: %d clusters in %d rounds, %d nodes below them, stack need below a cluster root %d\n", n_top, rounds, n_cw, lower_need);
+            fb.scene_absmax = amax;
+            if (n_top == 1) {
+                d->cw_nodes = d_lower;
+                d->n_cw_nodes = size_t(n_cw);
+                fb.max_depth = lower_need;
+                fb.cw_stack_need = lower_need;
+            } else {
+                FastBvh up;
+                build_fast_upper(top_boxes.data(), n_top, lower_need, up);
+                const int n_up = int(up.cw.size());
+                for (CwNode& nd : up.cw)
+                    for (int c = 0; c < 4; c++)
+                        if (nd.child[c] < 0 && nd.child[c] != kFastEmpty) {            // cluster -> its root node, or its triangles if it is one leaf
+                            const int32_t r = top_roots[size_t(-1 - nd.child[c])];
+                            nd.child[c] = r >= 0 ? n_up + r : r;
+                        }
+                e = hipMalloc(reinterpret_cast<void**>(&d->cw_nodes), size_t(n_up + n_cw) * sizeof(CwNode));
+                if (e == hipSuccess) e = hipMemcpy(d->cw_nodes, up.cw.data(), size_t(n_up) * sizeof(CwNode), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpyAsync(d->cw_nodes + n_up, d_lower, size_t(n_cw) * sizeof(CwNode), hipMemcpyDeviceToDevice, d->stream);
+                if (e == hipSuccess) e = device_offset_children(d->cw_nodes + n_up, n_cw, n_up, d->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+                (void)hipFree(d_lower);
+                if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("device build of the fast hierarchy: ") + hipGetErrorString(e));
+                d->n_cw_nodes = size_t(n_up) + size_t(n_cw);
+                fb.max_depth = up.max_depth + lower_need;
+                fb.cw_stack_need = up.cw_stack_need;             // includes lower_need
+            }
+            }
+        }
+        if (build_mode != MCPT_BUILD_DEVICE_SAH || ploc_fell_back) {
         hipError_t e = device_build_fast(d->tris, t, blo, bhi, kPerLeaf, kClusterLevels, &d_lower, &d->fast_tris, &n_cw, &levels, &n_top, &top_boxes, &amax, d->stream);
         if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("device build of the fast hierarchy: ") + hipGetErrorString(e));
         fb.scene_absmax = amax;
@@ -676,6 +735,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
             d->n_cw_nodes = size_t(n_up) + size_t(n_cw);
             fb.max_depth = up.max_depth + levels;
             fb.cw_stack_need = up.cw_stack_need;             // includes the clusters' 3 * levels
+        }
         }
     } else {
         int32_t* d_slots = nullptr;

@@ -498,11 +498,14 @@ def test_render_scene_outputs_and_resume(mcpt, tmp_path):
     sc.close()
 
 
+@pytest.mark.parametrize("mode", ["fast", "sah"])
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis", "synthetic"])
-def test_fast_hierarchy_built_on_device(mcpt, oracle, name):
+def test_fast_hierarchy_built_on_device(mcpt, oracle, name, mode):
     """MCPT_BUILD_DEVICE_FAST: the culling hierarchy is a 4-wide tree over the Morton order, built by build_kernels.hip instead
-    of the host's SAH builder.  It only culls, so nothing may change: the fast walk on it agrees with the reference-shaped walk
-    ray for ray, bit for bit, and the image equals the one rendered on the host-built hierarchy."""
+    of the host's SAH builder; MCPT_BUILD_DEVICE_SAH: clusters grown on the GPU by locally-ordered clustering and collapsed there,
+    the host's builder over the clusters.  A hierarchy only culls, so nothing may change: the fast walk on it agrees with the
+    reference-shaped walk ray for ray, bit for bit, and the image equals the one rendered on the host-built hierarchy.  The clustered
+    tree must also be about as good as the host's SAH tree: at most 1.3x its node steps + triangle visits on these rays."""
     from montecarlopathtracing_amd import synthetic
     if name == "synthetic":
         g = synthetic.generate(60000, width=96, height=54)
@@ -520,7 +523,7 @@ def test_fast_hierarchy_built_on_device(mcpt, oracle, name):
         rays = make_rays(osc, 50000, seed=31)
         osc.close()
         host = mcpt.Device(sc, 0, build=mcpt.BUILD_HOST)
-    dev = mcpt.Device(sc, 0, build=mcpt.BUILD_DEVICE_FAST)
+    dev = mcpt.Device(sc, 0, build=mcpt.BUILD_DEVICE_FAST if mode == "fast" else mcpt.BUILD_DEVICE_SAH)
     st_h, st_d = mcpt.Stats(), mcpt.Stats()
     f0, t0, p0, n0 = host.ray_intersect(rays, stats=st_h)
     f1, t1, p1, n1 = dev.ray_intersect(rays, stats=st_d)
@@ -533,6 +536,8 @@ def test_fast_hierarchy_built_on_device(mcpt, oracle, name):
         assert np.array_equal(_bits(t[h]), _bits(t1[h])) and np.array_equal(_bits(p[h]), _bits(p1[h])) and np.array_equal(_bits(n[h]), _bits(n1[h]))
     # it really was the fast walk on the device-built tree: far fewer steps than the exhaustive reference walk
     assert st_d.node_visits < 0.2 * rays.shape[0] * sc.info.num_faces / 8
+    if mode == "sah":
+        assert st_d.node_visits + st_d.tri_tests <= 1.3 * (st_h.node_visits + st_h.tri_tests), (st_d.node_visits, st_h.node_visits, st_d.tri_tests, st_h.tri_tests)
     dev.set_trace_mode(mcpt.TRACE_FAST)
     a = host.generateImg(4, seed=5)
     b = dev.generateImg(4, seed=5)
@@ -931,6 +936,20 @@ def test_ten_million_triangles(mcpt):
     fr, tr, pr, nr = a.ray_intersect(rays[:64])
     a.set_trace_mode(mcpt.TRACE_FAST)
     assert np.array_equal(fr, fa[:64]) and np.array_equal(_bits(tr[fr >= 0]), _bits(ta[:64][fr >= 0]))
+    # the same scene with the hierarchy grown on the GPU by locally-ordered clustering (MCPT_BUILD_DEVICE_SAH): same answers, and about
+    # the host tree's work per ray (the Morton-cluster build b needs ~1.9x its node visits)
+    import time
+    t0 = time.time()
+    c = mcpt.Device(sc, 0, build=mcpt.BUILD_DEVICE_SAH)
+    t_build = time.time() - t0
+    sa, sc_ = mcpt.Stats(), mcpt.Stats()
+    a.ray_intersect(rays, stats=sa)
+    fc, tc, pc, nc = c.ray_intersect(rays, stats=sc_)
+    assert np.array_equal(fa, fc) and np.array_equal(_bits(ta[h]), _bits(tc[h])) and np.array_equal(_bits(pa[h]), _bits(pc[h])) and np.array_equal(_bits(na[h]), _bits(nc[h]))
+    assert sc_.node_visits + sc_.tri_tests <= 1.3 * (sa.node_visits + sa.tri_tests), (sc_.node_visits, sa.node_visits, sc_.tri_tests, sa.tri_tests)
+    print("10 M triangles, MCPT_BUILD_DEVICE_SAH: device created in %.2f s; node visits %.2fx, triangle visits %.2fx the host tree's" % (
+        t_build, sc_.node_visits / sa.node_visits, sc_.tri_tests / sa.tri_tests))
+    c.close()
     ia = a.generateImg(4, seed=1)
     ib = b.generateImg(4, seed=1)
     assert ia.sum() > 0 and np.array_equal(_bits(ia), _bits(ib)) and np.array_equal(_bits(ia), _bits(a.generateImg(4, seed=1)))
