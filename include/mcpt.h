@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCPT_VERSION 103
+#define MCPT_VERSION 104
 
 #define MCPT_OK             0
 #define MCPT_ERR_IO        -1   /* a scene/texture/output file could not be opened */

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(mcpt):
     L = C.CDLL(_lib.LIB_PATH)
     for sym in sorted(declared):
         assert hasattr(L, sym), sym
-    assert mcpt.lib().mcpt_version() == 103
+    assert mcpt.lib().mcpt_version() == 104
 
 
 def test_no_cpu_fallback_and_error_codes(mcpt, tmp_path):
