@@ -43,7 +43,7 @@ COUNT_KEYS = ("rays", "node_visits", "tri_tests", "samples", "launches", "rays_p
               "dom_node_visits", "dom_tri_tests")
 
 
-def committed_profile(name_glob, build_id):
+def committed_profile(name_glob, build_id, kernel=None):
     """(path, json, reason): the newest profiles/rNN_final_<name> whose recorded build_id is the loaded library's.  bench.py cannot
     collect PMC counters of itself; tools/final_profile.sh does, with this same command, and stamps every file with the library's
     build id (a hash of the sources libmcpt.so was compiled from).  A profile of another build is not quoted."""
@@ -56,7 +56,7 @@ def committed_profile(name_glob, build_id):
             j = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if j.get("build_id") == build_id:
+        if j.get("build_id") == build_id and (kernel is None or j.get("kernel") == kernel):
             return f, j, None
     return None, None, ("the committed profiles (%s) were taken with another build of libmcpt.so than the one loaded (build id %s): "
                         "their counters are not quoted" % (", ".join(os.path.relpath(f, ROOT) for f in files[-2:]), build_id))
@@ -268,7 +268,7 @@ def run_capi(args):
         n_ranks_timed = n
     # ms_trace of a multi-GPU frame is the slowest rank's; launches are summed over ranks
     return {"elapsed": elapsed, "tot": tot, "world": n, "scene": scene, "scene_dir": scene_dir, "frame": frame_host, "extra": extra,
-            "build_id": M.build_id(), "launch_ranks": n_ranks_timed, "M": M}
+            "build_id": M.build_id(), "launch_ranks": n_ranks_timed, "M": M, "engine": scene.trace_engine()}
 
 
 def run_torch(args):
@@ -341,7 +341,7 @@ def run_torch(args):
     extra = {"launcher": "torch: one process per GPU, mcpt_render_device per rank, torch.distributed gather (backend %s)" % ("gloo, shared GPU rehearsal" if share_gpu else "nccl = RCCL"),
              "hip_runtime": M.hip_runtime_path(), "frames_in_flight": 1}
     return {"elapsed": elapsed, "tot": tot, "world": world, "scene": scene, "scene_dir": scene_dir, "frame": frame_host, "extra": extra,
-            "build_id": M.build_id(), "launch_ranks": world, "M": M}
+            "build_id": M.build_id(), "launch_ranks": world, "M": M, "engine": scene.trace_engine()}
 
 
 def main():
@@ -399,17 +399,19 @@ def main():
     # HBM bytes per launch and issue utilisation: NOT measured by this run (a process cannot read PMC counters of itself) -- quoted from
     # the committed rocprofv3 --pmc passes of this same command, and only when they were taken with the build that is loaded now
     traffic, traffic_src, issue = None, None, None
+    # the dominant kernel: one launch per bounce iteration of the closest-hit engine the library picked for this scene
+    dom_kernel = "k_wf_trace_pool" if res.get("engine") == "pool" else "k_wf_trace"
     headline = (args.scene == "cornell-box" and (args.width, args.height, args.spp) == (1280, 720, 256) and world == 1 and args.sim_world <= 1
                 and not args.pipeline)
     if headline:
-        tf, tj, why = committed_profile("r*_final_hbm_traffic.json", res["build_id"])
+        tf, tj, why = committed_profile("r*_final_hbm_traffic.json", res["build_id"], dom_kernel)
         if tj is not None:
             traffic = tj["bytes_per_launch"]
             traffic_src = ("from_committed_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per the gfx950 "
                            "note), taken with this build (%s); not measured in this run" % (os.path.relpath(tf, ROOT), res["build_id"]))
         else:
             traffic_src = why
-        uf, uj, why = committed_profile("r*_final_issue_utilisation.json", res["build_id"])
+        uf, uj, why = committed_profile("r*_final_issue_utilisation.json", res["build_id"], dom_kernel)
         if uj is not None:
             issue = uj
             issue["source"] = "from_committed_profile: %s, taken with this build; not measured in this run" % os.path.relpath(uf, ROOT)
@@ -437,7 +439,7 @@ def main():
         "rays_per_frame": rays / steps, "samples_per_frame": tot["samples"] / steps,
         "nodes_per_ray": tot["node_visits"] / max(1.0, rays), "tris_per_ray": tot["tri_tests"] / max(1.0, rays),
         "build_id": res["build_id"],
-        "roofline": {"bound": "hbm", "kernel": "k_wf_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": dom_kernel, "engine": res.get("engine"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_ms": avg_ms, "launches": tot["launches"],
                      "algorithmic_bytes_per_launch": per_launch,

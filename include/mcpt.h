@@ -180,6 +180,14 @@ void mcpt_device_free(mcpt_device*);
 #define MCPT_TRACE_FAST      0
 #define MCPT_TRACE_REFERENCE 1
 int  mcpt_device_set_trace_mode(mcpt_device*, int32_t mode);
+/* Which closest-hit engine MCPT_TRACE_FAST runs (same tests on the same triangles, identical results): the voting engine (one ray per
+ * lane in registers, csrc/trace_persistent.hpp) or the pool engine (the rays of a workgroup resident in LDS, csrc/trace_pool.hpp).  The
+ * library picks by scene size -- the pool engine where the hierarchy stays in the caches and the walk is bound by instruction issue
+ * (at most MCPT_POOL_MAX_TRIS triangles, default 131072) -- unless the environment says MCPT_TRACE_ENGINE=vote or =pool.
+ * Returns what a device created for this scene now would use. */
+#define MCPT_ENGINE_VOTE 0
+#define MCPT_ENGINE_POOL 1
+int  mcpt_scene_trace_engine(const mcpt_scene*);
 
 /* ---- closest hit (ray_intersect) ---- */
 /* rays: n x 6 doubles (origin xyz, direction xyz).  face[n] = .obj face index or -1, t[n], p[n*3], pn[n*3];

@@ -71,7 +71,7 @@ EXPORTS = [
     "mcpt_scene_get_leaf_order", "mcpt_scene_get_bvh_nodes", "mcpt_scene_find_index", "mcpt_scene_get_material",
     "mcpt_scene_get_light", "mcpt_morton_code", "mcpt_scene_fast_bvh_stats",
     "mcpt_device_create", "mcpt_device_create_ex", "mcpt_device_get_bvh_nodes", "mcpt_device_get_leaf_order", "mcpt_device_free",
-    "mcpt_device_set_trace_mode",
+    "mcpt_device_set_trace_mode", "mcpt_scene_trace_engine",
     "mcpt_trace_closest", "mcpt_trace_closest_device",
     "mcpt_render", "mcpt_render_device", "mcpt_device_collect_stats", "mcpt_sample_radiance", "mcpt_owned_pixels",
     "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_png_encode_deflate", "mcpt_write_png_deflate", "mcpt_write_pfm",
@@ -126,6 +126,7 @@ def lib():
     L.mcpt_device_free.argtypes = [P]
     L.mcpt_device_free.restype = None
     L.mcpt_device_set_trace_mode.argtypes = [P, C.c_int32]
+    L.mcpt_scene_trace_engine.argtypes = [P]
     L.mcpt_trace_closest.argtypes = [P, D, C.c_int64, I32, D, D, D, C.POINTER(Stats)]
     L.mcpt_trace_closest_device.argtypes = [P, P, C.c_int64, P, P, P, P, P]
     L.mcpt_render.argtypes = [P, C.POINTER(RenderParams), D, C.POINTER(Stats)]

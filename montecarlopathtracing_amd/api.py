@@ -159,6 +159,10 @@ class Scene:
         check(lib().mcpt_scene_get_light(self._h, i, name, _p(rad, C.c_double), _p(m, C.c_int32), _p(a, C.c_double)))
         return name.value.decode(), rad, int(m[0]), float(a[0])
 
+    def trace_engine(self):
+        """'pool' or 'vote': the closest-hit engine a device created for this scene now would run (mcpt_scene_trace_engine)"""
+        return "pool" if lib().mcpt_scene_trace_engine(self._h) == 1 else "vote"
+
     def fast_bvh_stats(self):
         n = np.zeros(1, dtype=np.int32)
         d = np.zeros(1, dtype=np.int32)

@@ -265,7 +265,7 @@ static void launch_persistent(const DScene& S, const Src& src, long long total, 
     const long long blocks_needed = (total + 255) / 256;
     const int g = (int)(blocks_needed < resident ? blocks_needed : resident);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    if (cfg.trace_pool) {
+    if (cfg.trace_pool && total < (1ll << 32)) {        // (the pool engine keeps a ray's slot number in 32 bits)
         const long long per_block = cfg.trace_block_rays * (MCPT_POOL_WAVES / 4);
         const long long nb = (total + per_block - 1) / per_block;
         const int gp = (int)(nb < cfg.cus ? nb : cfg.cus);

@@ -27,7 +27,7 @@ struct LaunchCfg {
     int array_grid_short = 0, primary_grid_short = 0;   // ... short stack
     long long trace_block_rays = 2048;              // MCPT_TRACE_BLOCK_RAYS: a block of k_wf_trace is started per this many rays
     int min_chunk = 256, max_chunk = 2048;          // MCPT_TRACE_MIN_CHUNK / MAX_CHUNK: ray slots per queue claim
-    int trace_pool = 0;                             // MCPT_TRACE_ENGINE=pool: k_wf_trace_pool (rays resident in LDS) instead of k_wf_trace
+    int trace_pool = 0;                             // the pool engine (rays resident in LDS: k_wf_trace_pool, k_trace_pool) instead of the voting engine
 };
 void init_launch_cfg(LaunchCfg& cfg);               // wavefront.hip (calls init_launch_cfg_closest of kernels.hip)
 void init_launch_cfg_closest(LaunchCfg& cfg);

@@ -27,7 +27,7 @@ namespace mcpt {
 #define MCPT_POOL_WAVES 16
 #endif
 #ifndef MCPT_POOL_KT
-#define MCPT_POOL_KT 13             /* ray slots per lane (<= 16: one 16-bit mask per class) */
+#define MCPT_POOL_KT 16             /* ray slots per lane (<= 16: one 16-bit mask per class) */
 #endif
 #ifndef MCPT_POOL_STACK
 #define MCPT_POOL_STACK 16
@@ -40,7 +40,7 @@ namespace mcpt {
 #define MCPT_POOL_PREFETCH 0
 #endif
 #ifndef MCPT_POOL_CACHE_N
-#define MCPT_POOL_CACHE_N 88         /* nodes of the top of the tree held in LDS */
+#define MCPT_POOL_CACHE_N 0         /* nodes of the top of the tree held in LDS */
 #endif
 #ifndef MCPT_POOL_STICKY
 #define MCPT_POOL_STICKY 0          /* a lane whose slot stays at a node keeps it for the wave's next node step (no filing, no claim) */
@@ -64,9 +64,7 @@ namespace mcpt {
 struct alignas(16) PoolOxy { double ox, oy; };
 struct alignas(16) PoolOzDx { double oz, dx; };
 struct alignas(16) PoolDyz { double dy, dz; };
-struct alignas(16) PoolRcp { float rx, ry, rz, px; };       // 1/d as floats, first pad of make_rayf
-struct alignas(8) PoolPyz { float py, pz; };
-struct alignas(16) PoolBest { double best_t, best_px; };
+struct alignas(16) PoolRcp { float rx, ry, rz, limit; };    // 1/d as floats; the walk's current limit
 
 // Every array is [k][lane] (a 16-byte group per lane where a step wants the words together, else one word per lane): consecutive lanes
 // touch consecutive banks whatever their k, so no access of a step has a bank conflict.  (Single words inside 16-byte groups were
@@ -77,18 +75,15 @@ struct PoolLds {
     PoolOzDx ozdx[KT * 64];
     PoolDyz dyz[KT * 64];
     PoolRcp rcp[KT * 64];
-    PoolBest best[KT * 64];
-    PoolPyz pyz[KT * 64];
-    long long q[KT * 64];                   // the ray's slot in the source
-    float limit[KT * 64], margin[KT * 64];
+    double best_t[KT * 64];                 // the leader's product (p.x - o.x) * (1 / d.x); its hit point is formed again when the ray is finished
+    unsigned int q[KT * 64];                // the ray's slot in the source (launches of 2^32 slots and more take the voting engine)
     int cur[KT * 64];                       // node to step on / first triangle slot of the leaf
-    int tri_m[KT * 64];                     // leaf: number of triangles; exact class: mask of the survivors
     int best_leaf[KT * 64];
-    int spf[KT * 64];                       // stack entries (bits 0-7) | flags
+    int spf[KT * 64];                       // stack entries (bits 0-7) | flags | leaf: number of triangles, exact class: survivors (bits 16-23)
     int stack[SCAP * KT * 64];              // [entry][k][lane]
     unsigned long long mask[64];            // [lane]: class c in bits 16c .. 16c+15
     int tbl[NW * 64];                       // refill: rank among the fetched rays -> lane that holds it
-    uint4 nodes[MCPT_POOL_CACHE_N * 4];     // the top of the tree (trace_fast.hpp: NodeCache)
+    uint4 nodes[MCPT_POOL_CACHE_N ? MCPT_POOL_CACHE_N * 4 : 1];     // the top of the tree (trace_fast.hpp: NodeCache)
     unsigned int live;                      // slots that may still carry a ray
     unsigned int dry;                       // waves whose supply of source slots has run out
 };
@@ -159,7 +154,17 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 #endif
     };
 
-    // the top of the slot's stack becomes its work (cur, tri_m, spf are written); returns the class it waits for
+    // Culling pads and pruning margin are recomputed from the floats a step has at hand instead of being carried in the slot (16 bytes
+    // of 184): in fp32, rounded so that they are never below the values make_rayf / the voting engine use (those have a factor 2.6 of
+    // slack over the error they cover) -- a larger pad or margin only culls less; the decisions at the leaves are untouched.
+    const float s3f = __double2float_ru(3.0 * F.absmax), absmax_f = __double2float_ru(F.absmax);
+    auto pad_of = [&](float of, float rf_) __attribute__((always_inline)) { return (0x1p-20f * 1.00001f) * ((fabsf(of) + s3f) * fabsf(rf_)); };
+    auto margin_of = [&](const float of[3], const PoolRcp& a4) __attribute__((always_inline)) {
+        const float rmax = fmaxf(fmaxf(fabsf(a4.rx), fabsf(a4.ry)), fabsf(a4.rz));
+        const float scale = fmaxf(fmaxf(absmax_f, fabsf(of[0])), fmaxf(fabsf(of[1]), fabsf(of[2])));
+        return rmax <= 0.99e6f ? (1.0000001e-9f * 1.00001f) * (scale * rmax) : __builtin_inff();
+    };
+    // the top of the slot's stack becomes its work (cur, spf are written); returns the class it waits for
     auto pop_next = [&](int idx, int k, int spf) __attribute__((always_inline)) -> int {
         int sp = spf & 255;
         if (sp == 0) return C_FIN;
@@ -170,8 +175,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
         touch_next(node, first, cnt);
         L.cur[idx] = first;
-        if (!node) L.tri_m[idx] = cnt;
-        L.spf[idx] = (spf & ~255) | sp;
+        L.spf[idx] = (spf & 0xff00) | sp | (node ? 0 : cnt << 16);
         return node ? C_INNER : C_LEAF;
     };
 
@@ -256,8 +260,8 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
             if (have) {
                 const int cur = L.cur[idx];
                 const int spf = L.spf[idx];
-                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolRcp a4 = L.rcp[idx]; const PoolPyz a5 = L.pyz[idx];
-                const float limit = L.limit[idx];
+                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolRcp a4 = L.rcp[idx];
+                const float limit = a4.limit;
                 int sp = spf & 255;
                 if (sp > stack_cap - 3) {        // three pushes must fit: the ray goes to the one-lane walk
                     L.spf[idx] = spf | F_AMBIG; nc = C_FIN; refused = true;
@@ -265,7 +269,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     RayF rf;
                     rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
                     rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
-                    rf.pad[0] = a4.px; rf.pad[1] = a5.py; rf.pad[2] = a5.pz;
+                    rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
                     const CwHits h = cw_step(nodes, cur, ncache, rf, limit);
                     junk += pf; pf = 0;
                     if (h.ref[3] != MCPT_FAST_EMPTY) { L.stack[(sp * KT + k) * 64 + lane] = h.ref[3]; sp++; }
@@ -277,8 +281,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     const int ref = -1 - nxt;
                     const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
                     if (!none) { touch_next(node, first, cnt); L.cur[idx] = first; }
-                    if (!node && !none) L.tri_m[idx] = cnt;
-                    L.spf[idx] = (spf & ~255) | sp;
+                    L.spf[idx] = (spf & 0xff00) | sp | ((!node && !none) ? cnt << 16 : 0);
                     nc = node ? C_INNER : (none ? C_FIN : C_LEAF);
                 }
             }
@@ -287,16 +290,17 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
             // ---------------------------------------------------------------- the triangles of a leaf through the fp32 pre-test
             if (have) {
                 const int cur = L.cur[idx];
-                const int cnt = L.tri_m[idx];
-                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
-                const float limit = L.limit[idx], margin = L.margin[idx];
+                const int spf0 = L.spf[idx];
+                const int cnt = (spf0 >> 16) & 255;
+                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx]; const PoolRcp a4 = L.rcp[idx];
+                const float of[3] = {(float)a0.ox, (float)a0.oy, (float)a1.oz};
+                const float limit = a4.limit, margin = margin_of(of, a4);
                 unsigned int surv = 0;
                 w.tris += cnt;
 #if MCPT_PRE_TEST
                 if (!pre) surv = (1u << cnt) - 1u;
                 else {
                     Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
-                    const float of[3] = {(float)a0.ox, (float)a0.oy, (float)a1.oz};
                     const PreRay pr = make_pre_ray(F, r, of, margin);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                     for (int k0 = 0; k0 < cnt; k0 += MCPT_PRE_UNROLL) {
@@ -309,14 +313,14 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     }
                     junk += pf; pf = 0;
 #ifdef MCPT_PRE_CHECK
-                    const PoolBest a6 = L.best[idx];
-                    const bool found = (L.spf[idx] & F_FOUND) != 0;
+                    const double bt = L.best_t[idx];
+                    const bool found = (spf0 & F_FOUND) != 0;
                     for (int kk = 0; kk < cnt; kk++) {
                         if ((surv >> kk) & 1u) continue;
                         V3 pc;
                         if (tri_hit(tris + cur + kk, r, pc)) {
                             const double tc = (pc.x - r.o.x) / r.d.x;
-                            if (tc > 0.0 && (!found || tc <= a6.best_t * (1.0 + 0x1p-40))) { w.pre_wrong++; surv |= 1u << kk; }
+                            if (tc > 0.0 && (!found || tc <= bt * (1.0 + 0x1p-40))) { w.pre_wrong++; surv |= 1u << kk; }
                         }
                     }
 #endif
@@ -328,19 +332,19 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 #if MCPT_POOL_PREFETCH
                     { const DTri* tn = tris + cur + (__ffs((int)surv) - 1); MCPT_TOUCH(tn); MCPT_TOUCH(reinterpret_cast<const char*>(tn) + 64); }
 #endif
-                    L.tri_m[idx] = (int)surv; nc = C_EXACT;
+                    L.spf[idx] = (spf0 & 0xffff) | ((int)surv << 16); nc = C_EXACT;
                 }
-                else nc = pop_next(idx, k, L.spf[idx]);
+                else nc = pop_next(idx, k, spf0);
             }
         } else if (c == C_EXACT) {
             // ---------------------------------------------------------------- one surviving triangle through the reference's test
             c_exact += (unsigned int)n_have;
             if (have) {
                 const int cur = L.cur[idx];
-                int surv = L.tri_m[idx];
                 int spf = L.spf[idx];
+                int surv = (spf >> 16) & 255;
                 const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
-                const PoolBest a6 = L.best[idx];
+                const double best_t = L.best_t[idx];
                 Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
                 const int kk = __ffs(surv) - 1;
                 surv &= surv - 1;
@@ -353,18 +357,21 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 if (hit) {
                     const double ta = (p.x - r.o.x) * fast_rcp(r.d.x);
                     if (ta > 0.0) {
-                        const double band = a6.best_t * 0x1p-47;
-                        if (!found || ta < a6.best_t - band) {
-                            PoolBest nb; nb.best_t = ta; nb.best_px = p.x;
-                            L.best[idx] = nb; L.best_leaf[idx] = ti;
-                            L.limit[idx] = __double2float_ru((ta + ta * 0x1p-47) + (double)L.margin[idx]);
+                        const double band = best_t * 0x1p-47;
+                        if (!found || ta < best_t - band) {
+                            const PoolRcp a4 = L.rcp[idx];
+                            const float of[3] = {(float)a0.ox, (float)a0.oy, (float)a1.oz};
+                            L.best_t[idx] = ta; L.best_leaf[idx] = ti;
+                            L.rcp[idx].limit = __double2float_ru((ta + ta * 0x1p-47) + (double)margin_of(of, a4));
                             spf |= F_FOUND;
-                        } else if (!(ta > a6.best_t + band)) {
-                            const double t_new = (p.x - r.o.x) / r.d.x, t_old = (a6.best_px - r.o.x) / r.d.x;
-                            if (t_new < t_old || (t_new == t_old && tr->leaf < tris[L.best_leaf[idx]].leaf)) {
-                                PoolBest nb; nb.best_t = ta; nb.best_px = p.x;
-                                L.best[idx] = nb; L.best_leaf[idx] = ti;
-                            }
+                        } else if (!(ta > best_t + band)) {
+                            // (the leader's hit point again: the first two lines of the reference's test on its triangle, same operands, same bits)
+                            const DTri* lt = tris + L.best_leaf[idx];
+                            const V3 lv1 = ld3(lt->v1), ln = ld3(lt->n);
+                            const double tl = dot(lv1 - r.o, ln) / dot(ln, r.d);
+                            const double old_px = (r.o + r.d * tl).x;
+                            const double t_new = (p.x - r.o.x) / r.d.x, t_old = (old_px - r.o.x) / r.d.x;
+                            if (t_new < t_old || (t_new == t_old && tr->leaf < lt->leaf)) { L.best_t[idx] = ta; L.best_leaf[idx] = ti; }
                         }
                     }
                 }
@@ -372,10 +379,11 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 #if MCPT_POOL_PREFETCH
                     { const DTri* tn = tris + cur + (__ffs(surv) - 1); MCPT_TOUCH(tn); MCPT_TOUCH(reinterpret_cast<const char*>(tn) + 64); }
 #endif
-                    L.tri_m[idx] = surv; L.spf[idx] = spf; nc = C_EXACT;
+                    spf = (spf & 0xffff) | (surv << 16);
+                    L.spf[idx] = spf; nc = C_EXACT;
                 }
                 else nc = pop_next(idx, k, spf);
-                if (nc == C_FIN) L.spf[idx] = spf;
+                if (nc == C_FIN) L.spf[idx] = spf & 0xffff;
             }
         } else {
             // ---------------------------------------------------------------- results out, new rays in
@@ -383,8 +391,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 const int spf = L.spf[idx];
                 if (spf & F_RAY) {
                     const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
-                    const PoolBest a6 = L.best[idx];
-                    const long long slot = L.q[idx];
+                    const long long slot = (long long)L.q[idx];
                     Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
                     const bool found = (spf & F_FOUND) != 0;
                     bool ambiguous = (spf & F_AMBIG) != 0;
@@ -395,12 +402,12 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                         if (!own_box_hit(tr, r, rc)) ambiguous = true;
                         h.leaf = tr->leaf;
                         h.mat = tr->material;
-                        h.t = (a6.best_px - r.o.x) / r.d.x;
-                        if constexpr (Src::kWantsPoint) {
-                            const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
-                            const double t = dot(v1 - r.o, n) / dot(n, r.d);
-                            h.p = r.o + r.d * t;
-                        }
+                        // the hit point: the first two lines of intersect(Ray&, Face&, Vertex&) again -- same operands, same bits as when the
+                        // triangle was tested; t_k is divided out of its x (pathTracing.cpp:347)
+                        const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
+                        const double t = dot(v1 - r.o, n) / dot(n, r.d);
+                        h.p = r.o + r.d * t;
+                        h.t = (h.p.x - r.o.x) / r.d.x;
                     }
                     if (ambiguous) {
                         const unsigned int at = atomicAdd(&queue->slow_count, 1u);
@@ -456,20 +463,14 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 r.d.x = __shfl(nr.d.x, from, 64); r.d.y = __shfl(nr.d.y, from, 64); r.d.z = __shfl(nr.d.z, from, 64);
                 if (got) {
                     const V3 rcp = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
-                    const double rmax = fmax(fmax(fabs(rcp.x), fabs(rcp.y)), fabs(rcp.z));
-                    const double scale = fmax(fmax(F.absmax, fabs(r.o.x)), fmax(fabs(r.o.y), fabs(r.o.z)));
-                    const RayF rf = make_rayf(F, r, rcp);
                     PoolOxy b0; b0.ox = r.o.x; b0.oy = r.o.y;
                     PoolOzDx b1; b1.oz = r.o.z; b1.dx = r.d.x;
                     PoolDyz b2; b2.dy = r.d.y; b2.dz = r.d.z;
-                    PoolRcp b4; b4.rx = rf.r[0]; b4.ry = rf.r[1]; b4.rz = rf.r[2]; b4.px = rf.pad[0];
-                    PoolPyz b5; b5.py = rf.pad[1]; b5.pz = rf.pad[2];
-                    PoolBest b6; b6.best_t = 0; b6.best_px = 0;
-                    L.oxy[idx] = b0; L.ozdx[idx] = b1; L.dyz[idx] = b2; L.rcp[idx] = b4; L.pyz[idx] = b5; L.best[idx] = b6;
-                    L.limit[idx] = __builtin_inff();
-                    L.margin[idx] = rmax <= 1e6 ? __double2float_ru(1.0000001e-9 * scale * rmax) : __builtin_inff();
-                    L.cur[idx] = 0; L.tri_m[idx] = 0; L.best_leaf[idx] = -1; L.spf[idx] = F_RAY;
-                    L.q[idx] = next + from;
+                    PoolRcp b4; b4.rx = (float)rcp.x; b4.ry = (float)rcp.y; b4.rz = (float)rcp.z; b4.limit = __builtin_inff();
+                    L.oxy[idx] = b0; L.ozdx[idx] = b1; L.dyz[idx] = b2; L.rcp[idx] = b4;
+                    L.best_t[idx] = 0;
+                    L.cur[idx] = 0; L.best_leaf[idx] = -1; L.spf[idx] = F_RAY;
+                    L.q[idx] = (unsigned int)(next + from);
                     MCPT_TOUCH(nodes);
                     nc = C_INNER;
                 }

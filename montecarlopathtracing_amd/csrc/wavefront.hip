@@ -721,8 +721,7 @@ void init_launch_cfg(LaunchCfg& cfg)
     c = e ? std::atoi(e) : 0;
     cfg.max_chunk = c >= 64 ? c / 64 * 64 : 2048;
     if (cfg.max_chunk < cfg.min_chunk) cfg.max_chunk = cfg.min_chunk;
-    e = std::getenv("MCPT_TRACE_ENGINE");
-    cfg.trace_pool = (e && std::strcmp(e, "pool") == 0) ? 1 : 0;
+    cfg.trace_pool = 0;             // (mcpt_device_create picks the engine from the scene: capi.cpp: trace_engine_for)
     init_launch_cfg_closest(cfg);
 }
 
@@ -750,7 +749,7 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
     const long long blocks_needed = (total + cfg.trace_block_rays - 1) / cfg.trace_block_rays;
     const int g = (int)(blocks_needed < resident ? blocks_needed : resident);
     (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
-    if (cfg.trace_pool) {
+    if (cfg.trace_pool && total < (1ll << 32)) {        // (the pool engine keeps a ray's slot number in 32 bits)
         const long long per_block = cfg.trace_block_rays * (MCPT_POOL_WAVES / 4);
         const long long nb = (total + per_block - 1) / per_block;
         const int gp = (int)(nb < cfg.cus ? nb : cfg.cus);

@@ -279,10 +279,11 @@ def test_wavefront_iterations_against_megakernel_and_oracle(pair, oracle, mcpt, 
 
 
 def test_pool_engine_equals_voting_engine(pair, mcpt, monkeypatch):
-    """MCPT_TRACE_ENGINE=pool selects the closest-hit engine whose rays live in LDS (csrc/trace_pool.hpp: stateless wave steps on slots
-    claimed with LDS atomics) for the primary rays, mcpt_trace_closest and every k_wf_trace launch.  Same tests on the same triangles:
-    face / t / p / pn of 300 k rays (camera, interior, adversarial, on-surface origins) and whole wavefront frames with the hand-over
-    to k_wf_finish switched off must equal the default engine's bit for bit, with the same work (nodes stepped on, triangles visited)."""
+    """The library picks the closest-hit engine by scene size (mcpt_scene_trace_engine): the pool engine, whose rays live in LDS
+    (csrc/trace_pool.hpp: stateless wave steps on slots claimed with LDS atomics), for the primary rays, mcpt_trace_closest and every
+    trace launch of a small scene, the voting engine for large ones; MCPT_TRACE_ENGINE=vote / pool forces either.  Same tests on the
+    same triangles: face / t / p / pn of 300 k rays (camera, interior, adversarial, on-surface origins) and whole wavefront frames with
+    the hand-over to k_wf_finish switched off must be equal bit for bit, with the same work (nodes stepped on, triangles visited)."""
     name, osc, sc, dev0 = pair
     base = make_rays(osc, 200000, seed=21)
     f0, t0, p0, n0 = dev0.ray_intersect(base)
@@ -292,8 +293,11 @@ def test_pool_engine_equals_voting_engine(pair, mcpt, monkeypatch):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     rays = np.vstack([base, np.hstack([p0[hit] + 0.01 * d, d])[:60000], np.hstack([p0[hit], d])[:40000]])
     monkeypatch.setenv("MCPT_FINISH_PATHS", "0")
+    monkeypatch.setenv("MCPT_TRACE_ENGINE", "vote")
+    assert sc.trace_engine() == "vote"
     dv = mcpt.Device(sc, 0)
     monkeypatch.setenv("MCPT_TRACE_ENGINE", "pool")
+    assert sc.trace_engine() == "pool"
     dp = mcpt.Device(sc, 0)
     try:
         sv, sp = mcpt.Stats(), mcpt.Stats()

@@ -11,6 +11,8 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 300 python3 bench.py > $out/bench.json 2> $out/bench.err
+# the dominant kernel of that run (the engine the library picked for the scene)
+K=$(python3 -c "import json; print(json.load(open('$out/bench.json'))['roofline']['kernel'])")
 cut -c1-300 $out/bench.json
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats -o p --output-format csv -- python3 $root/bench.py --no-cpu-baseline > $out/stats.log 2>&1
@@ -19,10 +21,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c -d $out/pmc/$c -o pmc --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$c.log 2>&1
 done
 cd $root
-python3 tools/pmc_to_traffic.py $out/pmc k_wf_trace "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (cornell-box 1280x720 SPP 256)" $out/hbm_traffic.json > /dev/null
+python3 tools/pmc_to_traffic.py $out/pmc $K "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (cornell-box 1280x720 SPP 256)" $out/hbm_traffic.json > /dev/null
 python3 tools/pmc_summary.py $out/pmc k_wf > $out/pmc_hbm_traffic.txt
 bash tools/pmc_trace.sh gpurun_out/$tag/pmc_sq > $out/pmc_sq.log 2>&1
-python3 tools/pmc_issue.py $out/pmc_sq k_wf_trace $out/issue_utilisation.json "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (cornell-box 1280x720 SPP 256)"
+python3 tools/pmc_issue.py $out/pmc_sq $K $out/issue_utilisation.json "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (cornell-box 1280x720 SPP 256)"
 python3 tools/timeline.py $out/kt8/kt_kernel_trace.csv 1 > $out/timeline_one_eighth.txt
 for n in 2 4 8; do
   timeout -k 10 120 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sim-world $n > $out/sim_world_$n.json 2>> $out/bench.err
@@ -37,10 +39,10 @@ timeout -k 10 200 python3 bench.py --scene veach-mis --spp 100 --steps 5 --no-cp
 timeout -k 10 300 python3 bench.py --scene interior --steps 3 --no-cpu-baseline > $out/interior_spp256.json 2>> $out/bench.err
 timeout -k 10 400 python3 bench.py --scene synthetic --spp 16 --steps 3 --no-cpu-baseline > $out/synthetic10m_spp16.json 2>> $out/bench.err
 timeout -k 10 600 python3 bench.py --scene synthetic --width 3840 --height 2160 --spp 1024 --steps 1 --warmup 0 --no-cpu-baseline > $out/synthetic10m_3840x2160_spp1024.json 2>> $out/bench.err
-# lanes per phase, iterations and the pre-test's share from the in-kernel counters (diagnostic build: variants/libmcpt_diag.so, tools/build_variant.sh diag -DMCPT_TRACE_DIAG)
+# lanes per phase, iterations and the pre-test's share from the in-kernel counters (diagnostic build: variants/libmcpt_diag.so, tools/build_variant.sh diag "-DMCPT_TRACE_DIAG -DMCPT_POOL_DEBUG")
 if [ -f montecarlopathtracing_amd/csrc/variants/libmcpt_diag.so ]; then
   MCPT_LIB=montecarlopathtracing_amd/csrc/variants/libmcpt_diag.so MCPT_PRINT_DIAG=1 timeout -k 10 200 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/diag.json 2> $out/diag.err
-  grep -E "trace diag|k_wf_trace:|deferred|logic diag|finish diag" $out/diag.err | tail -5 > $out/trace_phases.txt
+  grep -E "trace diag|k_wf_trace:|deferred|logic diag|finish diag|pool class|pool:" $out/diag.err | tail -10 > $out/trace_phases.txt
   cat $out/trace_phases.txt
 fi
 for f in veach_mis_spp100 interior_spp256 synthetic10m_spp16 synthetic10m_3840x2160_spp1024; do python3 -c "import json; d=json.load(open('$out/$f.json')); print('$f', round(d['ms_per_step'],2), 'ms', round(d['value'],1), 'Mrays/s', round(d['nodes_per_ray'],1), round(d['tris_per_ray'],1))"; done
