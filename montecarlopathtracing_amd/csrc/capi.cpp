@@ -786,21 +786,23 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     }
     lap("culling hierarchy in HBM");
     if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
+    init_launch_cfg(d->cfg);
+    d->cfg.trace_pool = trace_engine_for(t) == MCPT_ENGINE_POOL ? 1 : 0;
+    // the pool engine keeps the stack entries of a ray beyond those it has in LDS in an area behind the deferred-ray list of the launch
+    const size_t spill_bytes = d->cfg.trace_pool ? pool_spill_bytes(d->cfg.cus) : 0;
     for (auto& f : d->slot) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.ctr), sizeof(DCounters)));
         HIP_TRY(hipMemset(f.ctr, 0, sizeof(DCounters)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.wf_counts), sizeof(WfCounts) * MCPT_WF_COUNT_SLOTS));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.queue), sizeof(TraceQueue)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.slow_list), size_t(d->slow_cap) * sizeof(long long)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.slow_list), size_t(d->slow_cap) * sizeof(long long) + spill_bytes));
         HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_ctr), sizeof(DCounters)));
     HIP_TRY(hipMemset(d->aux_ctr, 0, sizeof(DCounters)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_queue), sizeof(TraceQueue)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_slow_list), size_t(d->slow_cap) * sizeof(long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_slow_list), size_t(d->slow_cap) * sizeof(long long) + spill_bytes));
     if (const char* e = std::getenv("MCPT_FINISH_PATHS")) d->finish_threshold = std::atoll(e);
-    init_launch_cfg(d->cfg);
-    d->cfg.trace_pool = trace_engine_for(t) == MCPT_ENGINE_POOL ? 1 : 0;
     if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
         const double v = std::atof(gb);
         if (v > 0.01) d->wf_budget_bytes = size_t(v * double(size_t(1) << 30));

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_trace_pool(DScene S, Src src, Tr
     __shared__ PoolLds<NW, KT, SCAP> L;
     LaneStats ls;
     Work w = {0, 0};
-    trace_pool<Src, NW, KT, SCAP>(S, src, queue, slow_list, slow_cap, chunk, L, w);
+    trace_pool<Src, NW, KT, SCAP>(S, src, queue, slow_list, slow_cap, chunk, L, w, reinterpret_cast<int*>(slow_list + slow_cap));
     ls.nodes = w.nodes; ls.tris = w.tris;
     { const unsigned long long tw = wave_sum(w.pre_wrong); if ((threadIdx.x & 63) == 0 && tw && ctr) atomicAdd(&ctr->pad[20], tw); }
     flush_stats(ctr, ls);

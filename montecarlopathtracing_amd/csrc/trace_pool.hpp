@@ -6,16 +6,18 @@
 // needs, runs it, writes back what changed and files the slot under its next class.
 //
 //   * Slot s = k * 64 + lane is only ever handled by lane `lane` (of any wave): every LDS access of a step is [field][k][lane], i.e.
-//     conflict free, and there is no queue between waves -- per lane one 64-bit LDS word holds the class sets as four 16-bit masks
+//     conflict free, and there is no queue between waves -- per lane two 64-bit LDS words hold the class sets, 32 bits each
 //     (bit k of class c: slot k * 64 + lane waits for a step of class c).  Claim = atomic AND that clears the bit (the caller owns the
-//     slot iff the bit was set in the value returned), filing = atomic OR.  A claimed slot is in no mask, so nothing else touches it.
+//     slot iff the bit was set in the value returned), filing = atomic OR.  A claimed slot is in no set, so nothing else touches it.
 //     No wave ever waits for another one: no barrier after the start, no spinning on data (the only sleep is "nothing claimable now").
 //   * A lane has work in class c if any of its KT slots (not held by another wave) waits for c: with a few slots per class that is
-//     nearly always, which is where the lanes per instruction come from.
+//     nearly always, which is where the lanes per instruction come from -- so a slot is kept small (120 bytes: fp64 ray, 1/d as
+//     floats, limit, leader, eight stack entries): every slot more per lane is worth one to two lanes per step.
 //   * LDS ordering: the LDS unit executes a wave's instructions in order; state writes precede the OR that files the slot, the reads
 //     follow the AND that claimed it.
-//   * The traversal stack is short (MCPT_POOL_STACK entries): a ray that would overflow it goes to the deferred list (one-lane walk with
-//     the deep stack), like in the short-stack shape of the persistent engine.
+//   * Only the first MCPT_POOL_STACK entries of a slot's traversal stack are in LDS; the deeper ones (a tenth of the rays get there)
+//     live in a global spill area behind the launch's deferred-ray list, [block][entry][slot].  A ray that would pass the walk's
+//     stack_cap goes to the deferred list (one-lane walk), like in the persistent engine.
 // The decisions are the persistent engine's, test for test (same cw_step, tri_pre_reject, tri_hit, ranking, own-box check at the end),
 // so results are bit-identical to it and to the reference-shaped walk.
 #pragma once
@@ -27,14 +29,18 @@ namespace mcpt {
 #define MCPT_POOL_WAVES 16
 #endif
 #ifndef MCPT_POOL_KT
-#define MCPT_POOL_KT 16             /* ray slots per lane (<= 16: one 16-bit mask per class) */
+#define MCPT_POOL_KT 20             /* ray slots per lane (<= 32: one 32-bit set per class) */
 #endif
 #ifndef MCPT_POOL_STACK
-#define MCPT_POOL_STACK 16
+#define MCPT_POOL_STACK 8           /* stack entries per slot in LDS */
 #endif
+#define MCPT_POOL_SPILL (MCPT_FAST_STACK - MCPT_POOL_STACK)      /* ... and beyond them in global memory (few rays go that deep) */
 // vote: the class with the largest weight x (lanes that can claim a slot of it) runs; ties go downstream (finish > exact > leaf > node)
 #ifndef MCPT_POOL_CLAIMS
 #define MCPT_POOL_CLAIMS 2             /* attempts of a lane to claim a slot in one step */
+#endif
+#ifndef MCPT_POOL_GRAB
+#define MCPT_POOL_GRAB 0           /* 1: a claim takes every slot of the class the word shows and hands back all but one (measured: 85.0 vs 81.7 ms, the hidden slots starve the other waves) */
 #endif
 #ifndef MCPT_POOL_PREFETCH
 #define MCPT_POOL_PREFETCH 0
@@ -81,7 +87,7 @@ struct PoolLds {
     int best_leaf[KT * 64];
     int spf[KT * 64];                       // stack entries (bits 0-7) | flags | leaf: number of triangles, exact class: survivors (bits 16-23)
     int stack[SCAP * KT * 64];              // [entry][k][lane]
-    unsigned long long mask[64];            // [lane]: class c in bits 16c .. 16c+15
+    unsigned long long mask[64 * 2];        // [lane][2]: class c in bits 32 (c & 1) .. + 31 of word c >> 1
     int tbl[NW * 64];                       // refill: rank among the fetched rays -> lane that holds it
     uint4 nodes[MCPT_POOL_CACHE_N ? MCPT_POOL_CACHE_N * 4 : 1];     // the top of the tree (trace_fast.hpp: NodeCache)
     unsigned int live;                      // slots that may still carry a ray
@@ -99,9 +105,10 @@ __device__ __forceinline__ long long uni(long long v)
 
 template <class Src, int NW, int KT, int SCAP>
 __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, TraceQueue* queue, long long* __restrict__ slow_list,
-                                           unsigned int slow_cap, long long chunk, PoolLds<NW, KT, SCAP>& L, Work& w)
+                                           unsigned int slow_cap, long long chunk, PoolLds<NW, KT, SCAP>& L, Work& w,
+                                           int* __restrict__ spill /* [block][MCPT_POOL_SPILL][KT * 64] stack entries beyond SCAP, or null */)
 {
-    static_assert(KT <= 16, "one 16-bit mask per class");
+    static_assert(KT <= 32, "one 32-bit set per class");
     enum { C_INNER = 0, C_LEAF = 1, C_EXACT = 2, C_FIN = 3, C_DEAD = 4 };
     enum { F_FOUND = 256, F_AMBIG = 512, F_RAY = 1024 };
     const DFast& F = S.fast;
@@ -112,13 +119,23 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     const long long small = chunk < MCPT_TAIL_CHUNK ? chunk : MCPT_TAIL_CHUNK;
     const long long big_tickets = (total - total / 8) / chunk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int stack_cap = F.stack_cap < SCAP ? F.stack_cap : SCAP;
+    const int stack_max = spill ? SCAP + MCPT_POOL_SPILL : SCAP;
+    const int stack_cap = F.stack_cap < stack_max ? F.stack_cap : stack_max;
+    int* __restrict__ my_spill = spill ? spill + (size_t)blockIdx.x * MCPT_POOL_SPILL * (KT * 64) : nullptr;
+    // entry e of slot (k, lane): in LDS below SCAP, else in this block's part of the spill area
+    auto st_put = [&](int e, int k, int v) __attribute__((always_inline)) {
+        if (e < SCAP) L.stack[(e * KT + k) * 64 + lane] = v;
+        else my_spill[((e - SCAP) * KT + k) * 64 + lane] = v;
+    };
+    auto st_get = [&](int e, int k) __attribute__((always_inline)) -> int {
+        return e < SCAP ? L.stack[(e * KT + k) * 64 + lane] : my_spill[((e - SCAP) * KT + k) * 64 + lane];
+    };
 
     // every slot starts in the finish class without a ray: the first steps of every wave are refills
     for (int k = wave; k < KT; k += NW) L.spf[k * 64 + lane] = 0;
     const NodeCache ncache = {L.nodes, F.cached < MCPT_POOL_CACHE_N ? F.cached : MCPT_POOL_CACHE_N};
     { const uint4* g = reinterpret_cast<const uint4*>(nodes); for (int i = threadIdx.x; i < ncache.n * 4; i += NW * 64) L.nodes[i] = g[i]; }
-    if (wave == 0) L.mask[lane] = (unsigned long long)((1u << KT) - 1u) << (16 * C_FIN);
+    if (wave == 0) { L.mask[lane * 2] = 0ull; L.mask[lane * 2 + 1] = ((1ull << KT) - 1ull) << 32; }       // (C_FIN: upper half of word 1)
     if (threadIdx.x == 0) { L.live = KT * 64; L.dry = 0; }
     __syncthreads();
 
@@ -169,7 +186,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         int sp = spf & 255;
         if (sp == 0) return C_FIN;
         sp--;
-        const int nxt = L.stack[(sp * KT + k) * 64 + lane];
+        const int nxt = st_get(sp, k);
         const bool node = nxt >= 0;
         const int ref = -1 - nxt;
         const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
@@ -180,14 +197,15 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     };
 
     for (;;) {
-        const unsigned long long m = __hip_atomic_load(&L.mask[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int n_inner = __popcll(__ballot(keep || (m & 0xffffull) != 0));
-        const int n_leaf = __popcll(__ballot((m & 0xffff0000ull) != 0));
-        const int n_exact = __popcll(__ballot((m & 0xffff00000000ull) != 0));
+        const unsigned long long m0 = __hip_atomic_load(&L.mask[lane * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned long long m1 = __hip_atomic_load(&L.mask[lane * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int n_inner = __popcll(__ballot(keep || (unsigned int)m0 != 0u));
+        const int n_leaf = __popcll(__ballot((m0 >> 32) != 0ull));
+        const int n_exact = __popcll(__ballot((unsigned int)m1 != 0u));
         // A wave's claim on source slots is private (a chunk per ticket): once the tickets are gone, a wave without a chunk leaves the
         // finish class to the waves that still have rays to hand out; a slot is retired only when every wave of the block is dry.
         const bool fin_ok = !queue_empty || uni((int)__hip_atomic_load(&L.dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == NW;
-        const int n_fin = fin_ok ? __popcll(__ballot((m >> 48) != 0)) : 0;
+        const int n_fin = fin_ok ? __popcll(__ballot((m1 >> 32) != 0ull)) : 0;
         if (!(n_inner | n_leaf | n_exact | n_fin)) {
             // (no lane keeps a slot here: n_inner counts them)
             if (uni((int)__hip_atomic_load(&L.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) break;
@@ -214,7 +232,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         c = uni(c);
         // slots kept for a node step that is not the next step after all are filed now
         if (c != C_INNER && __ballot(keep)) {
-            if (keep) __hip_atomic_fetch_or(&L.mask[lane], 1ull << (16 * C_INNER + keep_k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (keep) __hip_atomic_fetch_or(&L.mask[lane * 2], 1ull << keep_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             keep = false;
         }
 
@@ -223,23 +241,47 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         bool have = keep;
         int k = keep_k;
         keep = false;
-        unsigned long long cm = m;
+        unsigned long long cm = c < 2 ? m0 : m1;
+        unsigned long long* const mword = &L.mask[lane * 2 + (c >> 1)];
+        const int mshift = 32 * (c & 1);
+#if MCPT_POOL_GRAB
+        // Claim: take every slot of the class this lane's word shows NOW (one atomic that clears the class's half of the word), keep one,
+        // hand the others straight back.  A claim made on the mask read a moment ago loses whenever another wave's lane of the same index
+        // went for the same bit in between (with 16 waves: a sixth of the lanes); this one only fails if nothing is there at all.
+        {
+            const bool want = !have && (unsigned int)(cm >> mshift) != 0u;
+            if (want) {
+                const unsigned long long cls = 0xffffffffull << mshift;
+                const unsigned long long old = __hip_atomic_fetch_and(mword, ~cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned int got = (unsigned int)(old >> mshift);
+                if (got) {
+                    int kk;
+                    if (wave & 1) { const unsigned int lo = got & (0xffffffffu >> (31 - rot)); kk = 31 - __clz((int)(lo ? lo : got)); }
+                    else { const unsigned int hi = got & (0xffffffffu << rot); kk = __ffs((int)(hi ? hi : got)) - 1; }
+                    const unsigned int rest = got & ~(1u << kk);
+                    if (rest) __hip_atomic_fetch_or(mword, (unsigned long long)rest << mshift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    have = true; k = kk;
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int attempt = 0; attempt < MCPT_POOL_CLAIMS; attempt++) {
-            const unsigned int mc = (unsigned int)(cm >> (16 * c)) & 0xffffu;
+            const unsigned int mc = (unsigned int)(cm >> mshift);
             const bool want = !have && mc != 0u;
             if (attempt && !__ballot(want)) break;
             if (want) {
                 int kk;
-                if (wave & 1) { const unsigned int lo = mc & (0xffffu >> (15 - rot)); kk = 31 - __clz((int)(lo ? lo : mc)); }
-                else { const unsigned int hi = mc & (0xffffu << rot); kk = __ffs((int)(hi ? hi : mc)) - 1; }
-                const unsigned long long bit = 1ull << (16 * c + kk);
-                const unsigned long long old = __hip_atomic_fetch_and(&L.mask[lane], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (wave & 1) { const unsigned int lo = mc & (0xffffffffu >> (31 - rot)); kk = 31 - __clz((int)(lo ? lo : mc)); }
+                else { const unsigned int hi = mc & (0xffffffffu << rot); kk = __ffs((int)(hi ? hi : mc)) - 1; }
+                const unsigned long long bit = 1ull << (mshift + kk);
+                const unsigned long long old = __hip_atomic_fetch_and(mword, ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 have = (old & bit) != 0ull;
                 k = kk;
                 cm = old & ~bit;
             }
         }
+#endif
         rot = rot + 1 == KT ? 0 : rot + 1;
         const unsigned long long hv = __ballot(have);
 #ifdef MCPT_POOL_DEBUG
@@ -272,11 +314,11 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
                     const CwHits h = cw_step(nodes, cur, ncache, rf, limit);
                     junk += pf; pf = 0;
-                    if (h.ref[3] != MCPT_FAST_EMPTY) { L.stack[(sp * KT + k) * 64 + lane] = h.ref[3]; sp++; }
-                    if (h.ref[2] != MCPT_FAST_EMPTY) { L.stack[(sp * KT + k) * 64 + lane] = h.ref[2]; sp++; }
-                    if (h.ref[1] != MCPT_FAST_EMPTY) { L.stack[(sp * KT + k) * 64 + lane] = h.ref[1]; sp++; }
+                    if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
+                    if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
+                    if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
                     int nxt = h.ref[0];
-                    if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = L.stack[(sp * KT + k) * 64 + lane]; }
+                    if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = st_get(sp, k); }
                     const bool node = nxt >= 0, none = nxt == MCPT_FAST_EMPTY;
                     const int ref = -1 - nxt;
                     const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
@@ -495,7 +537,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         if (have && c == C_INNER && nc == C_INNER) { keep = true; keep_k = k; nc = C_DEAD; }      // (not filed: it stays with this lane)
 #endif
         if (have && nc != C_DEAD)
-            __hip_atomic_fetch_or(&L.mask[lane], 1ull << (16 * nc + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&L.mask[lane * 2 + (nc >> 1)], 1ull << (32 * (nc & 1) + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #undef MCPT_TOUCH
     junk += pf;

@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_wf_trace_pool(DScene S, WfArgs a
 #ifdef MCPT_POOL_DEBUG
     if (a.ctr) w.dbg = a.ctr->dbg;
 #endif
-    trace_pool<WfRaySource, NW, KT, SCAP>(S, src, queue, slow_list, slow_cap, chunk, L, w);
+    trace_pool<WfRaySource, NW, KT, SCAP>(S, src, queue, slow_list, slow_cap, chunk, L, w, reinterpret_cast<int*>(slow_list + slow_cap));
     ls.nodes = w.nodes; ls.tris = w.tris;
     if (a.ctr) {
         const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays), te = wave_sum(w.exact);
@@ -684,6 +684,11 @@ void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool f
     unsigned g = grid_for(n_upper, 1024, first ? cfg.logic_first : cfg.logic_rest);
     if (first) hipLaunchKernelGGL(k_wf_logic<true>, dim3(g), dim3(256), 0, st, S, a);
     else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a);
+}
+
+size_t pool_spill_bytes(int cus)
+{
+    return size_t(cus > 0 ? cus : 256) * size_t(MCPT_POOL_SPILL) * size_t(MCPT_POOL_KT * 64) * sizeof(int);
 }
 
 int persistent_grid(const void* kernel, int cus)
