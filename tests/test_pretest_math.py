@@ -110,6 +110,50 @@ def test_pre_test_never_rejects_what_the_reference_accepts(mcpt, name):
     assert cands > 50 and rejected > 0.9 * n_rays * len(g)       # the test rejects nearly everything, and there were candidates to lose
 
 
+def _ru32(x):
+    """float64 array -> float32 rounded toward +inf (the device's __double2float_ru)"""
+    f = x.astype(np.float32)
+    low = f.astype(np.float64) < x
+    return np.where(low, np.nextafter(f, np.float32(np.inf)), f).astype(np.float32)
+
+
+def test_pool_engine_recomputed_pads_and_margin_are_never_smaller():
+    """csrc/trace_pool.hpp does not carry the culling pads and the pruning margin of a ray in its LDS slot: every step recomputes them in
+    fp32 from the floats it has at hand (pad_of, margin_of).  Culling is only safe with pads / margins at least as large as the ones
+    the voting engine derives in fp64 (trace_fast.hpp: make_rayf; trace_persistent.hpp: margin_f), so: the fp32 formulas, restated
+    here operation for operation in numpy float32, against the fp64 ones on two million random rays over eight decades of scene size."""
+    rng = np.random.default_rng(12)
+    n = 2_000_000
+    absmax = 10.0 ** rng.uniform(-3, 5, n)
+    o = (rng.random((n, 3)) * 2 - 1) * absmax[:, None] * rng.choice([1.0, 3.9], n)[:, None]
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::7, 0] *= 1e-5                                        # near-axis-parallel directions: large reciprocals
+    rcp = 1.0 / d
+    f32 = np.float32
+    # the voting engine (fp64, rounded up to float)
+    pad64 = _ru32(16.0 * 2.0 ** -24 * (np.abs(o) + 3.0 * absmax[:, None]) * np.abs(rcp) * 1.0000002)
+    rmax = np.abs(rcp).max(axis=1)
+    scale = np.maximum(absmax, np.abs(o).max(axis=1))
+    margin64 = np.where(rmax <= 1e6, _ru32(1.0000001e-9 * scale * rmax), f32(np.inf))
+    # the pool engine (fp32): of = (float)o, rf = (float)rcp, s3f = ru(3 absmax), absmax_f = ru(absmax)
+    of, rf = o.astype(f32), rcp.astype(f32)
+    s3f, absmax_f = _ru32(3.0 * absmax), _ru32(absmax)
+    c_pad = f32(2.0 ** -20) * f32(1.00001)
+    pad32 = c_pad * ((np.abs(of) + s3f[:, None]) * np.abs(rf))
+    rmax_f = np.abs(rf).max(axis=1)
+    scale_f = np.maximum(absmax_f, np.abs(of).max(axis=1))
+    c_m = f32(1.0000001e-9) * f32(1.00001)
+    margin32 = np.where(rmax_f <= f32(0.99e6), c_m * (scale_f * rmax_f), f32(np.inf))
+    assert pad32.dtype == np.float32 and margin32.dtype == np.float32
+    assert (pad32 >= pad64).all(), int((pad32 < pad64).sum())
+    assert (margin32 >= margin64).all(), int((margin32 < margin64).sum())
+    # ... and not wastefully larger: within 0.01 %
+    fin = np.isfinite(margin64) & np.isfinite(margin32)
+    assert fin.sum() > n // 2
+    assert (pad32 <= pad64 * f32(1.0001)).all() and (margin32[fin] <= margin64[fin] * f32(1.0001)).all()
+
+
 def test_bench_quotes_only_profiles_of_the_loaded_build(tmp_path):
     """bench.committed_profile: counters under profiles/ are quoted only when the file carries the build id asked for."""
     import json
