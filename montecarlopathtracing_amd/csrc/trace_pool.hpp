@@ -87,7 +87,7 @@ struct PoolLds {
     int best_leaf[KT * 64];
     int spf[KT * 64];                       // stack entries (bits 0-7) | flags | leaf: number of triangles, exact class: survivors (bits 16-23)
     int stack[SCAP * KT * 64];              // [entry][k][lane]
-    unsigned long long mask[64 * 2];        // [lane][2]: class c in bits 32 (c & 1) .. + 31 of word c >> 1
+    unsigned long long mask[2 * 64];        // [2][lane]: class c in bits 32 (c & 1) .. + 31 of word c >> 1 (8 bytes per lane: no bank conflict)
     int tbl[NW * 64];                       // refill: rank among the fetched rays -> lane that holds it
     uint4 nodes[MCPT_POOL_CACHE_N ? MCPT_POOL_CACHE_N * 4 : 1];     // the top of the tree (trace_fast.hpp: NodeCache)
     unsigned int live;                      // slots that may still carry a ray
@@ -135,7 +135,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     for (int k = wave; k < KT; k += NW) L.spf[k * 64 + lane] = 0;
     const NodeCache ncache = {L.nodes, F.cached < MCPT_POOL_CACHE_N ? F.cached : MCPT_POOL_CACHE_N};
     { const uint4* g = reinterpret_cast<const uint4*>(nodes); for (int i = threadIdx.x; i < ncache.n * 4; i += NW * 64) L.nodes[i] = g[i]; }
-    if (wave == 0) { L.mask[lane * 2] = 0ull; L.mask[lane * 2 + 1] = ((1ull << KT) - 1ull) << 32; }       // (C_FIN: upper half of word 1)
+    if (wave == 0) { L.mask[lane] = 0ull; L.mask[64 + lane] = ((1ull << KT) - 1ull) << 32; }       // (C_FIN: upper half of word 1)
     if (threadIdx.x == 0) { L.live = KT * 64; L.dry = 0; }
     __syncthreads();
 
@@ -197,8 +197,8 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     };
 
     for (;;) {
-        const unsigned long long m0 = __hip_atomic_load(&L.mask[lane * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const unsigned long long m1 = __hip_atomic_load(&L.mask[lane * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned long long m0 = __hip_atomic_load(&L.mask[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned long long m1 = __hip_atomic_load(&L.mask[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int n_inner = __popcll(__ballot(keep || (unsigned int)m0 != 0u));
         const int n_leaf = __popcll(__ballot((m0 >> 32) != 0ull));
         const int n_exact = __popcll(__ballot((unsigned int)m1 != 0u));
@@ -232,7 +232,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         c = uni(c);
         // slots kept for a node step that is not the next step after all are filed now
         if (c != C_INNER && __ballot(keep)) {
-            if (keep) __hip_atomic_fetch_or(&L.mask[lane * 2], 1ull << keep_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (keep) __hip_atomic_fetch_or(&L.mask[lane], 1ull << keep_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             keep = false;
         }
 
@@ -242,7 +242,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         int k = keep_k;
         keep = false;
         unsigned long long cm = c < 2 ? m0 : m1;
-        unsigned long long* const mword = &L.mask[lane * 2 + (c >> 1)];
+        unsigned long long* const mword = &L.mask[(c >> 1) * 64 + lane];
         const int mshift = 32 * (c & 1);
 #if MCPT_POOL_GRAB
         // Claim: take every slot of the class this lane's word shows NOW (one atomic that clears the class's half of the word), keep one,
@@ -537,7 +537,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         if (have && c == C_INNER && nc == C_INNER) { keep = true; keep_k = k; nc = C_DEAD; }      // (not filed: it stays with this lane)
 #endif
         if (have && nc != C_DEAD)
-            __hip_atomic_fetch_or(&L.mask[lane * 2 + (nc >> 1)], 1ull << (32 * (nc & 1) + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&L.mask[(nc >> 1) * 64 + lane], 1ull << (32 * (nc & 1) + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #undef MCPT_TOUCH
     junk += pf;
