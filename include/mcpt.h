@@ -163,10 +163,11 @@ int  mcpt_device_create(const mcpt_scene*, int32_t device_ordinal, mcpt_device**
  * those clusters (a quarter of the primitives) is built by the host's SAH builder.  2 s instead of 4 for a 10 M-triangle scene,
  * 1.3-1.5x the node visits per ray; results are identical (the hierarchy only culls). */
 #define MCPT_BUILD_DEVICE_FAST 2
-/* MCPT_BUILD_DEVICE with the culling hierarchy grown on the GPU at the quality of the host's SAH build: parallel locally-ordered
- * clustering (each cluster merges with the neighbour in Morton order that gives the smallest joint surface area) up to subtrees of 64
- * triangles, each collapsed on the GPU into compressed 4-wide nodes with leaves of up to four triangles; the host's SAH builder only
- * sees the clusters' boxes (a few percent of the primitives).  Results are identical (the hierarchy only culls). */
+/* MCPT_BUILD_DEVICE with the culling hierarchy grown on the GPU at close to the quality of the host's SAH build: parallel
+ * locally-ordered clustering (each cluster merges with the neighbour in Morton order that gives the smallest joint surface area) up to
+ * subtrees of 4096 triangles, of bounded height and bounded box area, each collapsed on the GPU into compressed 4-wide nodes with
+ * leaves of up to four triangles; the host's SAH builder only sees the clusters' boxes (3 272 for 10 M triangles).  0.8 s instead of
+ * 2.1 for a 10 M-triangle scene, 7-12 % more walk time than on the host's tree; results are identical (the hierarchy only culls). */
 #define MCPT_BUILD_DEVICE_SAH 3
 int  mcpt_device_create_ex(const mcpt_scene*, int32_t device_ordinal, int32_t build_mode, mcpt_device** out);
 int  mcpt_device_get_bvh_nodes(mcpt_device*, double* box6 /* Nr*6, may be NULL */, int32_t* leaf_face /* Nr, may be NULL */);

@@ -329,9 +329,9 @@ int mcpt_scene_get_light(const mcpt_scene* h, int32_t i, char name[64], double r
 uint32_t mcpt_morton_code(float x, float y, float z) { return morton_code(x, y, z); }
 
 // Engine of the fast walk for a scene of t triangles (include/mcpt.h: mcpt_scene_trace_engine).  Measured on MI355X, frame times pool /
-// vote: cornell-box (15 k triangles) 83.0 / 92.3 ms, veach-mis 152.6 / 160.7, one eighth of a cornell-box frame 14.6 / 15.3; the 204 k
-// triangle interior 259 / 250, 10 M triangles 57.5 / 52.8: where the walk waits for memory, the pool engine's longer chain of dependent
-// LDS and memory round trips per step costs more than its fuller lanes save.
+// vote: cornell-box (15 k triangles) 82.0 / 92.3 ms, veach-mis 147.5 / 160.7, one eighth of a cornell-box frame 13.9 / 15.3; the 204 k
+// triangle interior 253 / 250, 10 M triangles 56.3 / 52.8: where the walk waits for memory, the pool engine's longer chain of dependent
+// LDS and memory round trips per step costs what its fuller lanes save, or more.
 static int trace_engine_for(long long t)
 {
     if (const char* e = std::getenv("MCPT_TRACE_ENGINE")) {
