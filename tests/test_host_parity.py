@@ -35,6 +35,25 @@ def test_library_exports_every_declared_symbol(mcpt):
     assert mcpt.lib().mcpt_version() == 104
 
 
+def test_trace_engine_is_picked_by_scene_size(mcpt, monkeypatch):
+    """mcpt_scene_trace_engine (host logic, no GPU): the pool engine for scenes whose hierarchy stays in the caches (at most
+    MCPT_POOL_MAX_TRIS triangles, default 131072), the voting engine above; MCPT_TRACE_ENGINE forces either."""
+    sc = mcpt.Scene(SCENES, "cornell-box")
+    monkeypatch.delenv("MCPT_TRACE_ENGINE", raising=False)
+    monkeypatch.delenv("MCPT_POOL_MAX_TRIS", raising=False)
+    assert sc.info.num_faces < 131072 and sc.trace_engine() == "pool"
+    monkeypatch.setenv("MCPT_POOL_MAX_TRIS", str(sc.info.num_faces - 1))
+    assert sc.trace_engine() == "vote"
+    monkeypatch.setenv("MCPT_POOL_MAX_TRIS", str(sc.info.num_faces))
+    assert sc.trace_engine() == "pool"
+    monkeypatch.setenv("MCPT_TRACE_ENGINE", "vote")
+    assert sc.trace_engine() == "vote"
+    monkeypatch.setenv("MCPT_POOL_MAX_TRIS", "0")
+    monkeypatch.setenv("MCPT_TRACE_ENGINE", "pool")
+    assert sc.trace_engine() == "pool"
+    sc.close()
+
+
 def test_no_cpu_fallback_and_error_codes(mcpt, tmp_path):
     with pytest.raises(mcpt.McptError) as e:
         mcpt.Scene(str(tmp_path) + os.sep, "does-not-exist")
