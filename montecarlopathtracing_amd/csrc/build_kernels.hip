@@ -316,6 +316,8 @@ struct PlocArrays {
     int32_t* hgt;           // [2t] binary height (a triangle: 0)
     float* cost;            // [2t] SAH cost of the best way to finish the subtree (leaf or split), in units of area
     int32_t* leaf;          // [2t] 1: that best way is one leaf
+    int32_t* first;         // [2t] smallest triangle position below: a name of the cluster that does not depend on the order in which the
+                            //      merges of a round got their node numbers (ties between equal areas are broken by it)
 };
 
 __device__ __forceinline__ float ploc_area(const FBox& b)
@@ -326,7 +328,7 @@ __device__ __forceinline__ float ploc_area(const FBox& b)
 __global__ void k_ploc_init(int t, int32_t* __restrict__ cid, PlocArrays A, float cost_tri, float cost_leaf)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < t) { cid[i] = i; A.cnt[i] = 1; A.hgt[i] = 0; A.cost[i] = (cost_leaf + cost_tri) * ploc_area(A.box[i]); A.leaf[i] = 1; }
+    if (i < t) { cid[i] = i; A.cnt[i] = 1; A.hgt[i] = 0; A.cost[i] = (cost_leaf + cost_tri) * ploc_area(A.box[i]); A.leaf[i] = 1; A.first[i] = i; }
 }
 
 __device__ __forceinline__ float ploc_joint_area(const FBox& a, const FBox& b)
@@ -350,7 +352,7 @@ __global__ void k_ploc_nn(const int32_t* __restrict__ cid, int n, PlocArrays A, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int a = cid[i];
-    const int ca = A.cnt[a], ha = A.hgt[a];
+    const int ca = A.cnt[a], ha = A.hgt[a], fa = A.first[a];
     int best = -1;
     float best_area = __builtin_inff();
     unsigned int best_hash = 0xffffffffu;
@@ -365,7 +367,7 @@ __global__ void k_ploc_nn(const int32_t* __restrict__ cid, int n, PlocArrays A, 
             if (ar > max_area) continue;            // (keeps the clusters compact and a wall-sized triangle on its own: the top-down builder places those)
             // equal areas (regular meshes are full of them) are ordered by a hash of the pair: with "the lower position wins" a row of
             // equal triangles would merge one pair per round
-            const unsigned int hs = ploc_pair_hash(a, b);
+            const unsigned int hs = ploc_pair_hash(fa, A.first[b]);
             if (ar < best_area || (ar == best_area && hs < best_hash)) { best_area = ar; best_hash = hs; best = j; }
         }
     }
@@ -399,6 +401,7 @@ __global__ void k_ploc_merge(int32_t* __restrict__ cid, int n, const int32_t* __
     const bool leaf = c <= max_leaf && as_leaf <= as_split;
     A.cost[id] = leaf ? as_leaf : as_split;
     A.leaf[id] = leaf ? 1 : 0;
+    { const int f1 = A.first[a], f2 = A.first[b]; A.first[id] = f1 < f2 ? f1 : f2; }
     cid[i] = id;
 }
 __global__ void k_ploc_clear_partner(int32_t* __restrict__ cid, int n, const int32_t* __restrict__ nn)
@@ -584,6 +587,7 @@ hipError_t device_build_ploc(const DTri* leaf_tris, int t, const double lo[3], c
     PL_TRY(take(reinterpret_cast<void**>(&A.hgt), size_t(2) * t * 4));
     PL_TRY(take(reinterpret_cast<void**>(&A.cost), size_t(2) * t * 4));
     PL_TRY(take(reinterpret_cast<void**>(&A.leaf), size_t(2) * t * 4));
+    PL_TRY(take(reinterpret_cast<void**>(&A.first), size_t(2) * t * 4));
     PL_TRY(take(reinterpret_cast<void**>(&cid), size_t(t) * 4));
     PL_TRY(take(reinterpret_cast<void**>(&cid2), size_t(t) * 4));
     PL_TRY(take(reinterpret_cast<void**>(&nn), size_t(t) * 4));

@@ -542,6 +542,12 @@ def test_fast_hierarchy_built_on_device(mcpt, oracle, name, mode):
     assert st_d.node_visits < 0.2 * rays.shape[0] * sc.info.num_faces / 8
     if mode == "sah":
         assert st_d.node_visits + st_d.tri_tests <= 1.3 * (st_h.node_visits + st_h.tri_tests), (st_d.node_visits, st_h.node_visits, st_d.tri_tests, st_h.tri_tests)
+        # the clustering is deterministic (ordered compaction, no atomics in the layout): a second build is the same tree
+        dev2 = mcpt.Device(sc, 0, build=mcpt.BUILD_DEVICE_SAH)
+        st_2 = mcpt.Stats()
+        f3, t3, p3, n3 = dev2.ray_intersect(rays, stats=st_2)
+        dev2.close()
+        assert np.array_equal(f3, f1) and (st_2.node_visits, st_2.tri_tests) == (st_d.node_visits, st_d.tri_tests)
     dev.set_trace_mode(mcpt.TRACE_FAST)
     a = host.generateImg(4, seed=5)
     b = dev.generateImg(4, seed=5)
