@@ -335,12 +335,20 @@ uint32_t mcpt_morton_code(float x, float y, float z) { return morton_code(x, y, 
 static int trace_engine_for(long long t)
 {
     if (const char* e = std::getenv("MCPT_TRACE_ENGINE")) {
-        if (std::strcmp(e, "pool") == 0) return MCPT_ENGINE_POOL;
+        if (std::strcmp(e, "pool") == 0) return (mcpt_device_count() > 0 && !pool_engine_available()) ? MCPT_ENGINE_VOTE : MCPT_ENGINE_POOL;
         if (std::strcmp(e, "vote") == 0) return MCPT_ENGINE_VOTE;
     }
     long long max_tris = 1ll << 17;
     if (const char* e = std::getenv("MCPT_POOL_MAX_TRIS")) max_tris = std::atoll(e);
-    return t <= max_tris ? MCPT_ENGINE_POOL : MCPT_ENGINE_VOTE;
+    if (t > max_tris) return MCPT_ENGINE_VOTE;
+    // (a device that cannot hold the pool engine's workgroup -- 1024 threads, 159 KB of LDS -- runs the voting engine; without a device
+    // the answer is the policy's)
+    if (mcpt_device_count() > 0 && !pool_engine_available()) {
+        static bool told = false;
+        if (!told) { told = true; std::fprintf(stderr, "libmcpt: this device cannot hold the pool engine's workgroup; the voting engine runs instead\n"); }
+        return MCPT_ENGINE_VOTE;
+    }
+    return MCPT_ENGINE_POOL;
 }
 
 int mcpt_scene_trace_engine(const mcpt_scene* h)

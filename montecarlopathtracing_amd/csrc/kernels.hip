@@ -277,6 +277,17 @@ static void launch_persistent(const DScene& S, const Src& src, long long total, 
     hipLaunchKernelGGL(k_trace_slow<Src>, dim3(256), dim3(256), 0, st, S, src, queue, slow_list, slow_cap, ctr);
 }
 
+bool pool_engine_available_closest()
+{
+    int a = 0, b = 0;
+    const hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &a, reinterpret_cast<const void*>(k_trace_pool<ArrayRaySource, MCPT_POOL_WAVES, MCPT_POOL_KT, MCPT_POOL_STACK>), MCPT_POOL_WAVES * 64, 0);
+    const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &b, reinterpret_cast<const void*>(k_trace_pool<PrimaryRaySource, MCPT_POOL_WAVES, MCPT_POOL_KT, MCPT_POOL_STACK>), MCPT_POOL_WAVES * 64, 0);
+    if (e1 != hipSuccess || e2 != hipSuccess) (void)hipGetLastError();
+    return e1 == hipSuccess && e2 == hipSuccess && a >= 1 && b >= 1;
+}
+
 void init_launch_cfg_closest(LaunchCfg& cfg)
 {
     cfg.array_grid = persistent_grid(reinterpret_cast<const void*>(k_trace_persistent<ArrayRaySource, MCPT_FAST_STACK, 3>), cfg.cus);

@@ -29,6 +29,8 @@ struct LaunchCfg {
     int min_chunk = 256, max_chunk = 2048;          // MCPT_TRACE_MIN_CHUNK / MAX_CHUNK: ray slots per queue claim
     int trace_pool = 0;                             // the pool engine (rays resident in LDS: k_wf_trace_pool, k_trace_pool) instead of the voting engine
 };
+bool pool_engine_available();                      // wavefront.hip: the current device can hold a workgroup of the pool engine
+bool pool_engine_available_closest();              // kernels.hip: ... of its closest-hit forms
 size_t pool_spill_bytes(int cus);                  // wavefront.hip: bytes the pool engine wants behind a launch's deferred-ray list (stack entries beyond its LDS part)
 void init_launch_cfg(LaunchCfg& cfg);               // wavefront.hip (calls init_launch_cfg_closest of kernels.hip)
 void init_launch_cfg_closest(LaunchCfg& cfg);

@@ -686,6 +686,20 @@ void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool f
     else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a);
 }
 
+// Can this device hold a workgroup of the pool engine (1024 threads, 159 KB of LDS)?  Asked once per process; the closest-hit forms of
+// the kernel (kernels.hip) have the same footprint.
+bool pool_engine_available()
+{
+    static const int ok = [] {
+        int per_cu = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, reinterpret_cast<const void*>(k_wf_trace_pool<MCPT_POOL_WAVES, MCPT_POOL_KT, MCPT_POOL_STACK>), MCPT_POOL_WAVES * 64, 0);
+        if (e != hipSuccess) (void)hipGetLastError();
+        return (e == hipSuccess && per_cu >= 1 && pool_engine_available_closest()) ? 1 : 0;
+    }();
+    return ok != 0;
+}
+
 size_t pool_spill_bytes(int cus)
 {
     return size_t(cus > 0 ? cus : 256) * size_t(MCPT_POOL_SPILL) * size_t(MCPT_POOL_KT * 64) * sizeof(int);
@@ -759,7 +773,6 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
         const long long nb = (total + per_block - 1) / per_block;
         const int gp = (int)(nb < cfg.cus ? nb : cfg.cus);
         hipLaunchKernelGGL((k_wf_trace_pool<MCPT_POOL_WAVES, MCPT_POOL_KT, MCPT_POOL_STACK>), dim3(gp), dim3(MCPT_POOL_WAVES * 64), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
-        { const hipError_t le = hipGetLastError(); if (le != hipSuccess) std::fprintf(stderr, "k_wf_trace_pool launch: %s\n", hipGetErrorString(le)); }
     } else if (shallow) hipLaunchKernelGGL((k_wf_trace<kFastShortStack, 4>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
     else hipLaunchKernelGGL((k_wf_trace<MCPT_FAST_STACK, 3>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
     hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 512 ? g : 512), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);   // (blocks without work leave at once)
