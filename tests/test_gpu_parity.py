@@ -756,6 +756,8 @@ def test_bench_line_keeps_its_contract(tmp_path):
     assert (r["bytes_per_unit"]["node_visit"], r["bytes_per_unit"]["triangle_test"], r["bytes_per_unit"]["ray"]) == (32, 48, 64)
     assert r["record_bytes_rate_GBs"] > r["achieved"] and r["traffic"] is None and "not the headline workload" in r["traffic_source"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and "traffic" in r
+    # the dominant kernel is named after the engine the library picked for the scene (cornell-box: small, hence the pool engine)
+    assert (r["engine"], r["kernel"]) in (("pool", "k_wf_trace_pool"), ("vote", "k_wf_trace"))
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
 
