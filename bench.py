@@ -299,6 +299,10 @@ def run_torch(args):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
+    # This process imported torch first, so libmcpt.so's kernels run on the wheel's bundled HIP runtime, not on the release they were
+    # compiled against: the library refuses that unless told (mcpt_allow_runtime_mismatch); this launcher is the one place that tells
+    # it, and the line reports both versions under "hip_runtime".
+    M.allow_runtime_mismatch(True)
     scene, scene_dir, build_mode = make_scene(M, args, talk=rank == 0)
     dev = M.Device(scene, local_rank, build=build_mode)
     rr = DistributedRenderer(scene, dev, rank, world, torch_device=tdev, stage_on_cpu=share_gpu, pipeline=False)
@@ -339,7 +343,8 @@ def run_torch(args):
     if rank != 0:
         sys.exit(0)
     extra = {"launcher": "torch: one process per GPU, mcpt_render_device per rank, torch.distributed gather (backend %s)" % ("gloo, shared GPU rehearsal" if share_gpu else "nccl = RCCL"),
-             "hip_runtime": M.hip_runtime_path(), "frames_in_flight": 1}
+             "hip_runtime": M.hip_runtime_path(), "hip_versions": "compiled %d, runtime %d (mismatch allowed explicitly)" % M.hip_runtime_info()[:2],
+             "frames_in_flight": 1}
     return {"elapsed": elapsed, "tot": tot, "world": world, "scene": scene, "scene_dir": scene_dir, "frame": frame_host, "extra": extra,
             "build_id": M.build_id(), "launch_ranks": world, "M": M, "engine": scene.trace_engine()}
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MCPT_VERSION 104
+#define MCPT_VERSION 105
 
 #define MCPT_OK             0
 #define MCPT_ERR_IO        -1   /* a scene/texture/output file could not be opened */
@@ -95,6 +95,16 @@ int         mcpt_version(void);
 const char* mcpt_last_error(void);
 int         mcpt_device_count(void);                        /* number of HIP devices (0 without a GPU) */
 const char* mcpt_build_id(void);                            /* 16 hex digits: hash of the sources this library was compiled from */
+/* Which HIP runtime this process runs on (since 105).  libmcpt.so's kernels are built by one hipcc; the libamdhip64.so they run on is
+ * whichever the process loaded first under that soname (a Python process that imported torch has the wheel's bundled copy).  The first
+ * mcpt_device_create / mcpt_multi_create compares hipRuntimeGetVersion() with the HIP_VERSION the library was compiled against and
+ * returns MCPT_ERR_HIP, naming both and the runtime's file, when major.minor differ -- unless mcpt_allow_runtime_mismatch(1) was called
+ * (or MCPT_ALLOW_RUNTIME_MISMATCH=1 is set), which turns the refusal into one line on stderr.
+ *   mcpt_hip_runtime_info : versions encoded as HIP_VERSION (major * 10^7 + minor * 10^5 + patch); path = the file the runtime was loaded from
+ *   mcpt_hip_runtime_check: the comparison itself, a pure function (0 = compatible; msg receives the refusal's text) */
+int         mcpt_hip_runtime_info(int32_t* compiled, int32_t* runtime, char* path, int64_t cap);
+int         mcpt_hip_runtime_check(int32_t compiled, int32_t runtime, const char* runtime_path, char* msg, int64_t cap);
+void        mcpt_allow_runtime_mismatch(int32_t allow);
 
 /* ---- scene (host) ---- */
 /* Reads <path><filename>.obj/.mtl/.camera exactly like read_scene; textures named by map_Kd are looked up
@@ -112,6 +122,9 @@ int  mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out);
 #define MCPT_LOAD_MORTON_BOUNDS  4   /* Morton keys on the scene's bounding box (changes the leaf order, i.e. which of two
                                         equidistant triangles wins a tie; everything else is unchanged) */
 int  mcpt_scene_load_ex(const char* path, const char* filename, int32_t load_flags, mcpt_scene** out);
+/* Lifetime: a device (or mcpt_multi) created from a scene shares ownership of it -- the scene's memory goes with the last of
+ * mcpt_scene_free and the mcpt_device_free / mcpt_multi_free of everything created from it, in any order.  After mcpt_scene_free the
+ * caller's handle must not be passed to the library again. */
 void mcpt_scene_free(mcpt_scene*);
 /* The same scene_data from arrays instead of files (generated scenes: the 10 M-triangle stress scene would be ~1 GB of
  * .obj text).  Faces are given in the order the .obj would list them; Face::norm, Morton keys, per-material face
@@ -280,10 +293,11 @@ typedef struct {
     int32_t  gather;            /* MCPT_GATHER_* */
     const int32_t* devices;     /* NULL with num_devices > 0: ordinals 0..num_devices-1 */
 } mcpt_render_scene_options;
-/* The struct has grown with MCPT_VERSION and carries no size field.  mcpt_render_scene_ex reads only the fields every version
- * has had (seed .. output_prefix) and ignores the rest, so a caller compiled against an older header is safe;
- * mcpt_render_scene_opts (since 103) takes sizeof(mcpt_render_scene_options) as the caller's header defines it and reads exactly
- * that many bytes -- the entry point for everything after output_prefix. */
+/* The struct has grown with MCPT_VERSION and carries no size field.  mcpt_render_scene_ex -- the only entry point through version
+ * 102 -- reads the struct as it stood at 102, i.e. every field above: what a caller sets through it (load_flags, checkpoint,
+ * num_devices ...) is honoured, never silently dropped; a caller compiled against a 100 / 101 header must pass a zero-extended
+ * struct of this size.  mcpt_render_scene_opts (since 103) takes sizeof(mcpt_render_scene_options) as the caller's header defines
+ * it and reads exactly that many bytes: the entry point for any field added after 102, and the safe one for older headers. */
 int  mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options*, mcpt_stats* stats);
 int  mcpt_render_scene_opts(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options*, int64_t options_bytes, mcpt_stats* stats);
 

@@ -43,6 +43,26 @@ def hip_runtime_path():
     return ", ".join(found) if found else "unknown"
 
 
+def hip_runtime_info():
+    """(HIP_VERSION libmcpt.so was compiled against, the loaded runtime's version, the file that runtime came from)"""
+    comp, run = C.c_int32(0), C.c_int32(0)
+    path = C.create_string_buffer(512)
+    check(lib().mcpt_hip_runtime_info(C.byref(comp), C.byref(run), path, 512))
+    return comp.value, run.value, path.value.decode(errors="replace")
+
+
+def hip_runtime_check(compiled, runtime, runtime_path=""):
+    """the comparison mcpt_device_create makes (pure): (0 or MCPT_ERR_HIP, message)"""
+    msg = C.create_string_buffer(1024)
+    rc = lib().mcpt_hip_runtime_check(compiled, runtime, runtime_path.encode(), msg, 1024)
+    return rc, msg.value.decode(errors="replace")
+
+
+def allow_runtime_mismatch(allow=True):
+    """explicit consent to run libmcpt.so's kernels on a HIP runtime of another release (a process that imported torch first)"""
+    lib().mcpt_allow_runtime_mismatch(1 if allow else 0)
+
+
 def device_count():
     return lib().mcpt_device_count()
 

@@ -6,7 +6,7 @@
 
 #include <cstring>
 #include <vector>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include "build_kernels.hpp"
 #include "dev_common.hpp"
@@ -245,9 +245,9 @@ hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], c
         FastDomain dom;
         for (int a = 0; a < 3; a++) { dom.lo[a] = lo[a]; const double ext = hi[a] - lo[a]; dom.inv[a] = ext > 0 ? 1.0 / ext : 0.0; }
         hipLaunchKernelGGL(k_fast_keys, dim3((t + 255) / 256), dim3(256), 0, st, leaf_tris, t, dom, keys, idx);
-        rc = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st);
+        rc = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st);
         if (rc == hipSuccess) rc = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
-        if (rc == hipSuccess) rc = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st);
+        if (rc == hipSuccess) rc = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st);
         if (rc == hipSuccess) { hipLaunchKernelGGL(k_gather_tris, dim3((t + 255) / 256), dim3(256), 0, st, leaf_tris, idx_out, t, tris); rc = hipGetLastError(); }
         if (rc == hipSuccess) rc = hipStreamSynchronize(st);
         drop();
@@ -282,14 +282,17 @@ hipError_t device_build_fast(const DTri* leaf_tris, int t, const double lo[3], c
     }
     unsigned long long bits = 0;
     rc = hipGetLastError();
-    if (rc == hipSuccess) rc = hipMemcpyAsync(&bits, am, sizeof bits, hipMemcpyDeviceToHost, st);
+    // (pageable host memory -- a stack word, a vector -- is only ever touched by blocking copies after the stream has drained: an
+    // asynchronous copy into it goes through the runtime's pin-on-the-fly / staging paths, and an early return would leave a DMA
+    // pending into a dead frame)
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    if (rc == hipSuccess) rc = hipMemcpy(&bits, am, sizeof bits, hipMemcpyDeviceToHost);
     // exact boxes of the top level built here (nodes 0 .. size[L-1]-1): what the host's builder sees of each cluster; after the
     // last swap they are in `a`
     if (rc == hipSuccess && top_boxes) {
         top_boxes->resize(size_t(size[L - 1]) * 6);
-        rc = hipMemcpyAsync(top_boxes->data(), a, size_t(size[L - 1]) * sizeof(FBox), hipMemcpyDeviceToHost, st);
+        rc = hipMemcpy(top_boxes->data(), a, size_t(size[L - 1]) * sizeof(FBox), hipMemcpyDeviceToHost);
     }
-    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
     cleanup();
     if (rc != hipSuccess) { (void)hipFree(nodes); (void)hipFree(tris); return rc; }
     double v; std::memcpy(&v, &bits, sizeof v);
@@ -572,9 +575,9 @@ hipError_t device_build_ploc(const DTri* leaf_tris, int t, const double lo[3], c
     FastDomain dom;
     for (int a = 0; a < 3; a++) { dom.lo[a] = lo[a]; const double ext = hi[a] - lo[a]; dom.inv[a] = ext > 0 ? 1.0 / ext : 0.0; }
     hipLaunchKernelGGL(k_fast_keys, dim3((t + 255) / 256), dim3(256), 0, st, leaf_tris, t, dom, keys, idx);
-    PL_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st));
+    PL_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st));
     PL_TRY(take(&tmp, tmp_bytes));
-    PL_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st));
+    PL_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, idx, idx_out, t, 0, 63, st));
     hipLaunchKernelGGL(k_gather_tris, dim3((t + 255) / 256), dim3(256), 0, st, leaf_tris, idx_out, t, tris);
     // ---- clustering
     PlocArrays A;
@@ -601,7 +604,7 @@ hipError_t device_build_ploc(const DTri* leaf_tris, int t, const double lo[3], c
     const double sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
     const float max_area = area_fraction > 0 ? (float)((sx * sy + sy * sz + sz * sx) * area_fraction) : __builtin_inff();
     size_t sel_bytes = 0;
-    PL_TRY(hipcub::DeviceSelect::If(nullptr, sel_bytes, cid, cid2, counters + 1, t, PlocIsActive(), st));
+    PL_TRY(rocprim::select(nullptr, sel_bytes, cid, cid2, counters + 1, size_t(t), PlocIsActive(), st));
     void* sel_tmp = nullptr;
     PL_TRY(take(&sel_tmp, sel_bytes));
     int n_active = t, n_done = 0, n_rounds = 0;
@@ -611,12 +614,12 @@ hipError_t device_build_ploc(const DTri* leaf_tris, int t, const double lo[3], c
         hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(256), 0, st, cid, n_active, nn, A, t, counters, max_leaf, (float)cost_tri, 1.0f, (float)cost_leaf);
         hipLaunchKernelGGL(k_ploc_clear_partner, dim3(g), dim3(256), 0, st, cid, n_active, nn);
         size_t b1 = sel_bytes;
-        PL_TRY(hipcub::DeviceSelect::If(sel_tmp, b1, cid, done + n_done, counters + 2, n_active, PlocIsDone(), st));
+        PL_TRY(rocprim::select(sel_tmp, b1, cid, done + n_done, counters + 2, size_t(n_active), PlocIsDone(), st));
         size_t b2 = sel_bytes;
-        PL_TRY(hipcub::DeviceSelect::If(sel_tmp, b2, cid, cid2, counters + 1, n_active, PlocIsActive(), st));
+        PL_TRY(rocprim::select(sel_tmp, b2, cid, cid2, counters + 1, size_t(n_active), PlocIsActive(), st));
         int32_t h[2] = {0, 0};
-        PL_TRY(hipMemcpyAsync(h, counters + 1, 8, hipMemcpyDeviceToHost, st));
         PL_TRY(hipStreamSynchronize(st));
+        PL_TRY(hipMemcpy(h, counters + 1, 8, hipMemcpyDeviceToHost));       // blocking: h is a stack array
         n_active = h[0]; n_done += h[1];
         int32_t* sw = cid; cid = cid2; cid2 = sw;
         if (++n_rounds > 4096) { drop(); return hipErrorUnknown; }      // (every round finishes or merges at least one cluster)
@@ -649,17 +652,17 @@ hipError_t device_build_ploc(const DTri* leaf_tris, int t, const double lo[3], c
     hipLaunchKernelGGL(k_ploc_cluster_counts, dim3((nc + 255) / 256), dim3(256), 0, st, done, nc, A.cnt, tri_cnt);
     hipLaunchKernelGGL(k_ploc_collapse<false>, dim3(gc), dim3(128), 0, st, done, nc, A, t, max_leaf, budget, nullptr, nullptr, node_cnt, nullptr, nullptr, nullptr, nullptr, nullptr);
     size_t scan_bytes = 0;
-    PL_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, tri_cnt, tri_base, nc, st));
+    PL_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, tri_cnt, tri_base, int32_t(0), size_t(nc), rocprim::plus<int32_t>(), st));
     void* scan_tmp = nullptr;
     PL_TRY(take(&scan_tmp, scan_bytes));
     size_t sb = scan_bytes;
-    PL_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, sb, tri_cnt, tri_base, nc, st));
+    PL_TRY(rocprim::exclusive_scan(scan_tmp, sb, tri_cnt, tri_base, int32_t(0), size_t(nc), rocprim::plus<int32_t>(), st));
     sb = scan_bytes;
-    PL_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, sb, node_cnt, node_base, nc, st));
+    PL_TRY(rocprim::exclusive_scan(scan_tmp, sb, node_cnt, node_base, int32_t(0), size_t(nc), rocprim::plus<int32_t>(), st));
     int32_t last[2] = {0, 0};
-    PL_TRY(hipMemcpyAsync(&last[0], node_base + (nc - 1), 4, hipMemcpyDeviceToHost, st));
-    PL_TRY(hipMemcpyAsync(&last[1], node_cnt + (nc - 1), 4, hipMemcpyDeviceToHost, st));
     PL_TRY(hipStreamSynchronize(st));
+    PL_TRY(hipMemcpy(&last[0], node_base + (nc - 1), 4, hipMemcpyDeviceToHost));
+    PL_TRY(hipMemcpy(&last[1], node_cnt + (nc - 1), 4, hipMemcpyDeviceToHost));
     const int total = last[0] + last[1];
     CwNode* nodes = nullptr;
     DTri* out_tris = nullptr;
@@ -671,11 +674,11 @@ hipError_t device_build_ploc(const DTri* leaf_tris, int t, const double lo[3], c
     unsigned long long bits = 0;
     int32_t need = 0;
     rc = hipGetLastError();
-    if (rc == hipSuccess) rc = hipMemcpyAsync(&bits, am, 8, hipMemcpyDeviceToHost, st);
-    if (rc == hipSuccess) rc = hipMemcpyAsync(&need, counters + 3, 4, hipMemcpyDeviceToHost, st);
-    if (rc == hipSuccess && top_boxes) { top_boxes->resize(size_t(nc) * 6); rc = hipMemcpyAsync(top_boxes->data(), d_top, size_t(nc) * sizeof(FBox), hipMemcpyDeviceToHost, st); }
-    if (rc == hipSuccess && top_roots) { top_roots->resize(size_t(nc)); rc = hipMemcpyAsync(top_roots->data(), d_refs, size_t(nc) * 4, hipMemcpyDeviceToHost, st); }
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    if (rc == hipSuccess) rc = hipMemcpy(&bits, am, 8, hipMemcpyDeviceToHost);
+    if (rc == hipSuccess) rc = hipMemcpy(&need, counters + 3, 4, hipMemcpyDeviceToHost);
+    if (rc == hipSuccess && top_boxes) { top_boxes->resize(size_t(nc) * 6); rc = hipMemcpy(top_boxes->data(), d_top, size_t(nc) * sizeof(FBox), hipMemcpyDeviceToHost); }
+    if (rc == hipSuccess && top_roots) { top_roots->resize(size_t(nc)); rc = hipMemcpy(top_roots->data(), d_refs, size_t(nc) * 4, hipMemcpyDeviceToHost); }
     drop();
     if (rc != hipSuccess) { (void)hipFree(nodes); (void)hipFree(out_tris); return rc; }
     double v; std::memcpy(&v, &bits, sizeof v);
@@ -703,9 +706,9 @@ hipError_t device_build_reference(const BuildInputs& in, const mcpt_bvh_info& bi
     for (int a = 0; a < 3; a++) { dom.lo[a] = in.morton_lo[a]; dom.span[a] = in.morton_span[a]; }
     hipLaunchKernelGGL(k_morton_keys, dim3((t + 255) / 256), dim3(256), 0, st, in.v9, t, dom, keys, idx);
     // stable LSD radix sort of (key, face index) on the 30 key bits: equal keys keep .obj order (D2)
-    rc = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, idx, d_order, t, 0, 30, st);
+    rc = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, idx, d_order, t, 0, 30, st);
     if (rc == hipSuccess) rc = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
-    if (rc == hipSuccess) rc = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, idx, d_order, t, 0, 30, st);
+    if (rc == hipSuccess) rc = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, idx, d_order, t, 0, 30, st);
     if (rc != hipSuccess) { cleanup(); return rc; }
     const int leaf0 = ((1 << bi.Level) - 1) - (2 * (bi.Lv >> 1) - __builtin_popcount(unsigned(bi.Lv >> 1)));   // findIndex(2^Level - 1, Level)
     hipLaunchKernelGGL(k_fill_leaves, dim3((t + 255) / 256), dim3(256), 0, st, in.v9, in.vn9, in.vt6, in.nrm3, in.material, d_order, t, tris, shade,

@@ -1,6 +1,8 @@
 // C ABI of libmcpt.so (include/mcpt.h): host scene handles, device residency, and the launch sequences that
 // stand in for ray_intersect / generateImg / imshow / render_scene of the reference.
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_version.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -67,6 +69,10 @@ struct mcpt_scene {
     // The fast walk's culling hierarchy depends on the scene and the leaf order only: built once, shared by every device
     // created from this scene (one SAH build for the 8 GPUs of a node, not 8).
     mutable std::atomic<int> devices_created{0};      // mcpt_scene_set_resolution is refused once a device holds the camera
+    // Shared ownership: the caller's handle and every device created from the scene hold one reference each; the scene goes with the
+    // last of mcpt_scene_free / mcpt_device_free, in whichever order they come (a device keeps using the handle: the shared culling
+    // hierarchy, the counter above).
+    mutable std::atomic<int> refs{1};
     mutable std::mutex fast_mu;
     mutable std::shared_ptr<const FastBvh> fast_cached;
     mutable std::vector<int32_t> fast_order;
@@ -164,6 +170,63 @@ int mcpt_device_count(void)
     return n;
 }
 
+// ------------------------------------------------------------------------------------------------ which HIP runtime is this?
+// libmcpt.so's code objects are built by one hipcc; the libamdhip64.so they run on is whichever the process loaded first under that
+// soname (a Python process that imported torch has the wheel's bundled runtime, not /opt/rocm's).  Kernels built by a newer compiler on
+// an older runtime are the likeliest cause of the abort DESIGN 8a records, and nothing used to notice: now the first device creation
+// compares the two versions and refuses when major.minor differ, unless the caller has said it knows (mcpt_allow_runtime_mismatch).
+static std::atomic<int> g_allow_runtime_mismatch{0};
+
+void mcpt_allow_runtime_mismatch(int32_t allow) { g_allow_runtime_mismatch.store(allow ? 1 : 0); }
+
+// Pure comparison (CPU unit test): 0 when a library compiled against HIP `compiled` may run on runtime `runtime` (both encoded as
+// HIP_VERSION: major * 10^7 + minor * 10^5 + patch), else MCPT_ERR_HIP with a message naming both and the runtime's file.
+int mcpt_hip_runtime_check(int32_t compiled, int32_t runtime, const char* runtime_path, char* msg, int64_t cap)
+{
+    const int cmaj = compiled / 10000000, cmin = compiled / 100000 % 100, rmaj = runtime / 10000000, rmin = runtime / 100000 % 100;
+    const bool ok = compiled > 0 && runtime > 0 && cmaj == rmaj && cmin == rmin;
+    if (msg && cap > 0) {
+        if (ok) msg[0] = 0;
+        else
+            std::snprintf(msg, size_t(cap),
+                          "libmcpt.so was compiled against HIP %d.%d (%d) but this process runs on HIP runtime %d.%d (%d) loaded from %s: "
+                          "another libamdhip64.so was loaded first (a Python process that imported torch has the wheel's).  Load libmcpt.so "
+                          "before it, or call mcpt_allow_runtime_mismatch(1) / set MCPT_ALLOW_RUNTIME_MISMATCH=1 to run anyway",
+                          cmaj, cmin, compiled, rmaj, rmin, runtime, (runtime_path && runtime_path[0]) ? runtime_path : "(unknown)");
+    }
+    return ok ? MCPT_OK : MCPT_ERR_HIP;
+}
+
+int mcpt_hip_runtime_info(int32_t* compiled, int32_t* runtime, char* path, int64_t cap)
+{
+    if (compiled) *compiled = HIP_VERSION;
+    int rv = 0;
+    if (hipRuntimeGetVersion(&rv) != hipSuccess) { (void)hipGetLastError(); rv = 0; }
+    if (runtime) *runtime = rv;
+    if (path && cap > 0) {
+        path[0] = 0;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void*>(static_cast<hipError_t (*)(int*)>(&hipRuntimeGetVersion)), &info) && info.dli_fname) std::snprintf(path, size_t(cap), "%s", info.dli_fname);
+    }
+    return MCPT_OK;
+}
+
+// what mcpt_device_create / mcpt_multi_create ask before they touch a device
+static int runtime_gate()
+{
+    int32_t compiled = 0, runtime = 0;
+    char path[512], msg[1024];
+    mcpt_hip_runtime_info(&compiled, &runtime, path, sizeof path);
+    if (mcpt_hip_runtime_check(compiled, runtime, path, msg, sizeof msg) == MCPT_OK) return MCPT_OK;
+    const char* e = std::getenv("MCPT_ALLOW_RUNTIME_MISMATCH");
+    if (g_allow_runtime_mismatch.load() || (e && std::atoi(e) != 0)) {
+        static std::atomic<int> told{0};
+        if (!told.exchange(1)) std::fprintf(stderr, "libmcpt: %s -- running anyway, as asked\n", msg);
+        return MCPT_OK;
+    }
+    return fail(MCPT_ERR_HIP, msg);
+}
+
 // ------------------------------------------------------------------------------------------------ scene
 int mcpt_scene_load(const char* path, const char* filename, mcpt_scene** out) { return mcpt_scene_load_ex(path, filename, 0, out); }
 
@@ -181,7 +244,8 @@ int mcpt_scene_load_ex(const char* path, const char* filename, int32_t load_flag
     *out = h.release();
     return MCPT_OK;
 }
-void mcpt_scene_free(mcpt_scene* s) { delete s; }
+static void scene_release(const mcpt_scene* s) { if (s && s->refs.fetch_sub(1) == 1) delete s; }
+void mcpt_scene_free(mcpt_scene* s) { scene_release(s); }
 
 int mcpt_scene_create(const mcpt_scene_desc* dsc, int32_t flags, mcpt_scene** out)
 {
@@ -505,7 +569,7 @@ void mcpt_device_free(mcpt_device* d)
     if (d->look_stream) (void)hipStreamDestroy(d->look_stream);
     if (d->look_ev) (void)hipEventDestroy(d->look_ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
-    if (d->scene) d->scene->devices_created.fetch_sub(1);
+    if (d->scene) { d->scene->devices_created.fetch_sub(1); scene_release(d->scene); }
     delete d;
 }
 
@@ -524,6 +588,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     if (build_mode == MCPT_BUILD_HOST && !s.accel_built) return fail(MCPT_ERR_ARG, "scene has no host build; use MCPT_BUILD_DEVICE");
     int ndev = mcpt_device_count();
     if (ndev <= 0) return fail(MCPT_ERR_NO_DEVICE, "no HIP device available (libmcpt has no CPU fallback)");
+    if (const int gate = runtime_gate()) return gate;          // kernels of one hipcc on another release's runtime: refused
     if (ordinal < 0 || ordinal >= ndev) return fail(MCPT_ERR_NO_DEVICE, "device ordinal out of range");
     HIP_TRY(hipSetDevice(ordinal));
     std::unique_ptr<mcpt_device, void (*)(mcpt_device*)> d(new mcpt_device, mcpt_device_free);
@@ -848,6 +913,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     d->width = s.width; d->height = s.height;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->dirs), size_t(s.width) * s.height * 3 * sizeof(double)));
     h->devices_created.fetch_add(1);
+    h->refs.fetch_add(1);
     d->scene = h;
     *out = d.release();
     return MCPT_OK;
@@ -1480,12 +1546,15 @@ int mcpt_decode_jpeg(const char* file, int32_t* width, int32_t* height, uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------------ render_scene
-// The options struct has grown with the library version and carries no size of its own: mcpt_render_scene_ex reads the fields
-// every version has had (through output_prefix, MCPT_VERSION 100) and nothing behind them -- a caller built against an older
-// header hands over a shorter struct -- and mcpt_render_scene_opts takes the caller's sizeof and reads that many bytes.
+// The options struct grew with the library version (100: seed .. output_prefix; 101: .. reserved; 102: .. devices) and carries no size
+// of its own.  mcpt_render_scene_ex was the only entry point through version 102 and reads the struct as it stood then -- every field
+// of it: a caller that sets load_flags, a checkpoint or num_devices through it gets what it asked for, not a silently different
+// render -- so a caller compiled against a 100 / 101 header must hand over a zero-extended struct of that size.  Fields added after
+// 102 are reached through mcpt_render_scene_opts only, which takes the caller's sizeof and reads exactly that many bytes.
+static constexpr int64_t kOptionsBytesV102 = int64_t(offsetof(mcpt_render_scene_options, devices) + sizeof(const int32_t*));
 int mcpt_render_scene_ex(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options* opt, mcpt_stats* stats)
 {
-    return mcpt_render_scene_opts(path, filename, spp, opt, opt ? int64_t(offsetof(mcpt_render_scene_options, load_flags)) : 0, stats);
+    return mcpt_render_scene_opts(path, filename, spp, opt, opt ? kOptionsBytesV102 : 0, stats);
 }
 
 int mcpt_render_scene_opts(const char* path, const char* filename, int32_t spp, const mcpt_render_scene_options* opt, int64_t opt_bytes, mcpt_stats* stats)

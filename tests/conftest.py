@@ -12,6 +12,28 @@ for p in (ROOT, HERE):
 
 SCENES = os.path.join(ROOT, "scenes") + os.sep
 
+_EXTRA_DIR = None
+
+
+def extra_scene_dir():
+    """Directory holding the glassroom test scene (tests/scenes_extra: .obj/.mtl/.camera and its own checker texture) together with the
+    reference's cherry-wood texture, which the scene also uses and which is kept once, under scenes/ -- assembled in a temporary
+    directory on first use (textures are looked up next to the scene)."""
+    global _EXTRA_DIR
+    if _EXTRA_DIR is None:
+        import atexit
+        import shutil
+        import tempfile
+        d = tempfile.mkdtemp(prefix="mcpt_extra_")
+        atexit.register(shutil.rmtree, d, ignore_errors=True)
+        src = os.path.join(ROOT, "tests", "scenes_extra")
+        for f in os.listdir(src):
+            shutil.copy(os.path.join(src, f), d)
+        for f in ("cherry-wood-texture.jpg", "cherry-wood-texture.jpg.ppm"):
+            shutil.copy(os.path.join(SCENES, f), d)
+        _EXTRA_DIR = d + os.sep
+    return _EXTRA_DIR
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

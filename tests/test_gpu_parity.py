@@ -33,7 +33,9 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-EXTRA = os.path.join(ROOT, "tests", "scenes_extra") + os.sep
+from conftest import extra_scene_dir  # noqa: E402
+
+EXTRA = extra_scene_dir()
 
 
 # glassroom (tests/scenes_extra, CRLF files): refraction incl. total internal reflection (Ni 1.5), a Phong lobe (Ns 60), a
@@ -54,16 +56,56 @@ def pair(request, oracle, mcpt, tmp_path_factory):
     sc = mcpt.Scene(base, name, width=w, height=h)
     dev = mcpt.Device(sc, 0)
     yield name, osc, sc, dev
+    for d in _ENGINE_DEVS.pop(name, {}).values():
+        d.close()
+    for k in [k for k in _ORACLE_CACHE if k[0] == name]:
+        del _ORACLE_CACHE[k]
     dev.close()
     sc.close()
     osc.close()
 
 
-@pytest.mark.parametrize("mode", ["reference", "fast"])
-def test_closest_hit_bit_exact(pair, oracle, mcpt, mode):
+# The library picks the closest-hit engine by scene size (every test scene here is small: the pool engine).  The tests that hold the
+# HIP path to the ORACLE directly run once per engine -- the voting engine is what BASELINE configs 4 and 5 use -- on a device created
+# with MCPT_TRACE_ENGINE forced; what the oracle says is computed once per scene and kept for the second engine.
+_ENGINE_DEVS = {}
+_ORACLE_CACHE = {}
+ENGINES = ["pool", "vote"]
+
+
+def _engine_device(pair, mcpt, engine):
     name, osc, sc, dev = pair
+    devs = _ENGINE_DEVS.setdefault(name, {})
+    if engine not in devs:
+        old = os.environ.get("MCPT_TRACE_ENGINE")
+        os.environ["MCPT_TRACE_ENGINE"] = engine
+        try:
+            assert sc.trace_engine() == engine
+            devs[engine] = mcpt.Device(sc, 0)
+        finally:
+            if old is None:
+                del os.environ["MCPT_TRACE_ENGINE"]
+            else:
+                os.environ["MCPT_TRACE_ENGINE"] = old
+    return devs[engine]
+
+
+def _cached(name, what, fn):
+    key = (name, what)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("mode", ["reference", "fast"])
+def test_closest_hit_bit_exact(pair, oracle, mcpt, mode, engine):
+    name, osc, sc, _ = pair
+    if mode == "reference" and engine == "vote":
+        pytest.skip("the reference-shaped walk has no engine: covered by the pool-parametrised run")
+    dev = _engine_device(pair, mcpt, engine)
     rays = make_rays(osc, 40000, seed=11)
-    of, ot, op, opn = osc.trace_closest(rays)
+    of, ot, op, opn = _cached(name, "closest", lambda: osc.trace_closest(rays))
     st = mcpt.Stats()
     dev.set_trace_mode(mcpt.TRACE_REFERENCE if mode == "reference" else mcpt.TRACE_FAST)
     try:
@@ -161,19 +203,25 @@ def test_stack_overflow_is_handed_to_the_one_lane_walk(oracle, mcpt, monkeypatch
     plain.close(); sc.close(); osc.close()
 
 
-def test_sample_radiance(pair, oracle, mcpt):
-    name, osc, sc, dev = pair
+@pytest.mark.parametrize("engine", ENGINES)
+def test_sample_radiance(pair, oracle, mcpt, engine):
+    name, osc, sc, _ = pair
+    dev = _engine_device(pair, mcpt, engine)
     rng = np.random.default_rng(5)
     n = 6000
     pix = rng.integers(0, osc.width * osc.height, size=n).astype(np.int32)
     k = rng.integers(0, 64, size=n).astype(np.int32)
     g = dev.sample_radiance(77, pix, k)
-    o = np.zeros((n, 3))
-    on_surface = np.zeros(n, dtype=bool)            # the path has a refraction / total-reflection ray (starts on the surface)
-    for i, (p, kk) in enumerate(zip(pix, k)):
-        st = oracle.Stats()
-        o[i] = osc.sample_radiance(77, int(p // osc.width), int(p % osc.width), int(kk), stats=st)
-        on_surface[i] = st.rays_on_surface > 0
+
+    def from_oracle():
+        o = np.zeros((n, 3))
+        on_surface = np.zeros(n, dtype=bool)        # the path has a refraction / total-reflection ray (starts on the surface)
+        for i, (p, kk) in enumerate(zip(pix, k)):
+            st = oracle.Stats()
+            o[i] = osc.sample_radiance(77, int(p // osc.width), int(p % osc.width), int(kk), stats=st)
+            on_surface[i] = st.rays_on_surface > 0
+        return o, on_surface
+    o, on_surface = _cached(name, "samples", from_oracle)
     scale = np.maximum(np.abs(o).max(axis=1), 1e-12)
     err = np.abs(g - o).max(axis=1) / scale
     flip = err > REL_TOL
@@ -187,12 +235,19 @@ def test_sample_radiance(pair, oracle, mcpt):
     assert abs(g[same].sum() - o[same].sum()) <= 1e-9 * abs(o[same]).sum()
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("pipeline", ["wavefront", "megakernel"])
-def test_image_matches_oracle(pair, oracle, mcpt, pipeline):
-    name, osc, sc, dev = pair
+def test_image_matches_oracle(pair, oracle, mcpt, pipeline, engine):
+    name, osc, sc, _ = pair
+    if pipeline == "megakernel" and engine == "vote":
+        pytest.skip("the megakernel walks the reference-shaped tree one lane per sample: no engine involved beyond the primary rays")
+    dev = _engine_device(pair, mcpt, engine)
     spp = 8
-    ost = oracle.Stats()
-    ref = osc.render(spp, seed=3, stats=ost)
+
+    def from_oracle():
+        ost = oracle.Stats()
+        return osc.render(spp, seed=3, stats=ost), ost
+    ref, ost = _cached(name, "image", from_oracle)
     st = mcpt.Stats()
     img = dev.generateImg(spp, seed=3, stats=st, flags=mcpt.RENDER_MEGAKERNEL if pipeline == "megakernel" else 0)
     assert img.shape == ref.shape
@@ -312,7 +367,8 @@ def test_pool_engine_equals_voting_engine(pair, mcpt, monkeypatch):
             b = dp.generateImg(spp, seed=5, stats=sp)
             assert np.array_equal(_bits(a), _bits(b)), "%d channels differ" % int((_bits(a) != _bits(b)).sum())
             assert sv.dom_rays == sp.dom_rays
-            # (a ray whose walk needs more than the pool's 16 stack entries finishes in the one-lane walk, which counts elsewhere)
+            # (a ray the pool engine defers -- a walk deeper than its 8 LDS + 28 spill entries, a leader whose own box fails -- finishes in
+            # the one-lane walk, which counts elsewhere)
             assert abs(sv.dom_node_visits - sp.dom_node_visits) <= 0.01 * sv.dom_node_visits and abs(sv.dom_tri_tests - sp.dom_tri_tests) <= 0.01 * sv.dom_tri_tests
             assert sp.dom_rays > 0.9 * (sp.rays_shadow + sp.rays_bounce)
     finally:
@@ -402,9 +458,10 @@ print("done")
 
 
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis", "synthetic"])
-def test_device_build_equals_host_build(mcpt, name, tmp_path):
+def test_device_build_equals_host_build(mcpt, oracle, name, tmp_path):
     """Morton keys, stable radix sort, leaf records and the level-by-level union on the GPU (build_kernels.hip) against the
-    host build (bvh_build.cpp): every node box, the leaf order, and the rendered image, bit for bit."""
+    host build (bvh_build.cpp): every node box, the leaf order, and the rendered image, bit for bit -- and, for the scenes that exist as
+    files, the device's arrays against the ORACLE's directly (BVH.cpp:44-85, morton code.cpp, D2's stable order)."""
     from montecarlopathtracing_amd import synthetic
     if name == "synthetic":
         g = synthetic.generate(150000, width=96, height=54)     # above 2^17 triangles: the host's SAH build runs its worker threads
@@ -422,6 +479,13 @@ def test_device_build_equals_host_build(mcpt, name, tmp_path):
     assert np.array_equal(dev.leaf_order(), hl)
     assert np.array_equal(_bits(db), _bits(hb))
     assert np.array_equal(_bits(host.bvh_nodes()[0]), _bits(hb))
+    if name != "synthetic":
+        osc = oracle.OracleScene(SCENES + name, texture_dir=SCENES, width=96, height=54)
+        obox, olvl, oleaf = osc.bvh_nodes()
+        assert np.array_equal(dev.leaf_order(), osc.leaf_order())
+        assert np.array_equal(_bits(db), _bits(obox)), "%d of %d device-built node planes differ from the oracle's" % (int((_bits(db) != _bits(obox)).sum()), db.size)
+        assert np.array_equal(dleaf[olvl == olvl.max()], oleaf[olvl == olvl.max()])
+        osc.close()
     a = host.generateImg(4, seed=5)
     b = dev.generateImg(4, seed=5)
     assert np.array_equal(_bits(a), _bits(b)) and a.sum() > 0

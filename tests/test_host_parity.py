@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(mcpt):
     L = C.CDLL(_lib.LIB_PATH)
     for sym in sorted(declared):
         assert hasattr(L, sym), sym
-    assert mcpt.lib().mcpt_version() == 104
+    assert mcpt.lib().mcpt_version() == 105
 
 
 def test_trace_engine_is_picked_by_scene_size(mcpt, monkeypatch):

@@ -11,9 +11,15 @@ base="-O3 -std=c++17 -fPIC -ffp-contract=off -pthread -Wall -Wno-unused-function
 for f in kernels wavefront build_kernels; do
   $HIPCC $base --offload-arch=gfx950 -c -o variants/obj_$name/$f.o $f.hip &
 done
-for f in capi scene_loader bvh_build accel_build png_writer output_formats jpeg_decoder multi_device build_id; do
+for f in capi scene_loader bvh_build accel_build png_writer output_formats jpeg_decoder multi_device; do
   [ -f $f.cpp ] && g++ $base -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c -o variants/obj_$name/$f.o $f.cpp &
 done
+# mcpt_build_id() of a variant: the Makefile's recipe (sources + flags + arch) with this variant's extra flags, so that a variant never
+# carries the product's id and a profile taken with it is never quoted for the product
+srcs=$(ls *.cpp *.hip *.hpp | grep -v '^build_id.cpp$' | LC_ALL=C sort)
+id=$( (cat $srcs ../../include/mcpt.h Makefile; echo "$flags gfx950") | sha256sum | cut -c1-16)
+echo "extern \"C\" const char* mcpt_build_id(void) { return \"$id\"; }" > variants/obj_$name/build_id.cpp
+g++ $base -c -o variants/obj_$name/build_id.o variants/obj_$name/build_id.cpp &
 wait
 $HIPCC -shared -o variants/libmcpt_$name.so variants/obj_$name/*.o --offload-arch=gfx950
 echo built variants/libmcpt_$name.so

@@ -17,7 +17,8 @@ import oracle_lib as O  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 SCENES = os.path.join(ROOT, "scenes") + os.sep
-EXTRA = os.path.join(ROOT, "tests", "scenes_extra") + os.sep
+from conftest import extra_scene_dir  # noqa: E402
+EXTRA = extra_scene_dir()
 out = {}
 for name in ("cornell-box", "veach-mis", "glassroom", "interior"):
     w, h = 160, 90
