@@ -13,8 +13,9 @@
 //   * A lane has work in class c if any of its KT slots (not held by another wave) waits for c: with a few slots per class that is
 //     nearly always, which is where the lanes per instruction come from -- so a slot is kept small (120 bytes: fp64 ray, 1/d as
 //     floats, limit, leader, eight stack entries): every slot more per lane is worth one to two lanes per step.
-//   * LDS ordering: the LDS unit executes a wave's instructions in order; state writes precede the OR that files the slot, the reads
-//     follow the AND that claimed it.
+//   * Ordering between the wave that leaves a slot and the wave that takes it: the OR that files the slot is a release, the AND that
+//     claims it an acquire (workgroup scope) -- everything the step wrote, in LDS or in the global spill area, happens-before
+//     everything the next step reads (MCPT_POOL_ORDER).
 //   * Only the first MCPT_POOL_STACK entries of a slot's traversal stack are in LDS; the deeper ones (a tenth of the rays get there)
 //     live in a global spill area behind the launch's deferred-ray list, [block][entry][slot].  A ray that would pass the walk's
 //     stack_cap goes to the deferred list (one-lane walk), like in the persistent engine.
@@ -54,6 +55,21 @@ namespace mcpt {
 #ifndef MCPT_POOL_PREF
 #define MCPT_POOL_PREF 0            /* > 0: every wave has a class it prefers (its score counts (4 + PREF) / 4): simultaneous voters spread out */
 #endif
+// Hand-over of a slot from one wave to another.  What a step writes (LDS state, and stack entries beyond the eighth: plain stores to
+// the global spill area) must be visible to the wave that claims the slot next.  1 (default): the filing OR is a RELEASE and the claiming
+// AND an ACQUIRE at workgroup scope -- the memory model's own guarantee, for LDS and for the spill area alike.  0: relaxed atomics
+// between compiler barriers, which leans on the LDS unit executing a wave's instructions in order and says nothing about the spill
+// stores (they travel through the vector memory path, counted by vmcnt, not lgkmcnt) -- what rounds 3 ran; kept for A/B runs.
+#ifndef MCPT_POOL_ORDER
+#define MCPT_POOL_ORDER 1
+#endif
+#if MCPT_POOL_ORDER
+#define MCPT_POOL_CLAIM_ORDER __ATOMIC_ACQUIRE
+#define MCPT_POOL_FILE_ORDER __ATOMIC_RELEASE
+#else
+#define MCPT_POOL_CLAIM_ORDER __ATOMIC_RELAXED
+#define MCPT_POOL_FILE_ORDER __ATOMIC_RELAXED
+#endif
 #ifndef MCPT_PW_INNER
 #define MCPT_PW_INNER 4
 #endif
@@ -73,8 +89,10 @@ struct alignas(16) PoolDyz { double dy, dz; };
 struct alignas(16) PoolRcp { float rx, ry, rz, limit; };    // 1/d as floats; the walk's current limit
 
 // Every array is [k][lane] (a 16-byte group per lane where a step wants the words together, else one word per lane): consecutive lanes
-// touch consecutive banks whatever their k, so no access of a step has a bank conflict.  (Single words inside 16-byte groups were
-// 4-way conflicts: measured, a third of the LDS cycles.)
+// touch consecutive banks whatever their k, so a 4-byte access of a step has no bank conflict.  (Single words inside 16-byte groups
+// were 4-way conflicts: measured, a third of the LDS cycles.)  The 16-byte groups and the 8-byte words are not conflict-free in the
+// counter's sense: a 64-lane ds_read_b128 / ds_write_b128 covers 1 KB = eight passes over the 32 banks by construction, and
+// SQ_LDS_BANK_CONFLICT counts the passes beyond the first of every instruction (DESIGN section 6 has the account by instruction).
 template <int NW, int KT, int SCAP>
 struct PoolLds {
     PoolOxy oxy[KT * 64];
@@ -232,7 +250,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         c = uni(c);
         // slots kept for a node step that is not the next step after all are filed now
         if (c != C_INNER && __ballot(keep)) {
-            if (keep) __hip_atomic_fetch_or(&L.mask[lane], 1ull << keep_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (keep) __hip_atomic_fetch_or(&L.mask[lane], 1ull << keep_k, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
             keep = false;
         }
 
@@ -252,14 +270,14 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
             const bool want = !have && (unsigned int)(cm >> mshift) != 0u;
             if (want) {
                 const unsigned long long cls = 0xffffffffull << mshift;
-                const unsigned long long old = __hip_atomic_fetch_and(mword, ~cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long old = __hip_atomic_fetch_and(mword, ~cls, MCPT_POOL_CLAIM_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const unsigned int got = (unsigned int)(old >> mshift);
                 if (got) {
                     int kk;
                     if (wave & 1) { const unsigned int lo = got & (0xffffffffu >> (31 - rot)); kk = 31 - __clz((int)(lo ? lo : got)); }
                     else { const unsigned int hi = got & (0xffffffffu << rot); kk = __ffs((int)(hi ? hi : got)) - 1; }
                     const unsigned int rest = got & ~(1u << kk);
-                    if (rest) __hip_atomic_fetch_or(mword, (unsigned long long)rest << mshift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (rest) __hip_atomic_fetch_or(mword, (unsigned long long)rest << mshift, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
                     have = true; k = kk;
                 }
             }
@@ -275,7 +293,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 if (wave & 1) { const unsigned int lo = mc & (0xffffffffu >> (31 - rot)); kk = 31 - __clz((int)(lo ? lo : mc)); }
                 else { const unsigned int hi = mc & (0xffffffffu << rot); kk = __ffs((int)(hi ? hi : mc)) - 1; }
                 const unsigned long long bit = 1ull << (mshift + kk);
-                const unsigned long long old = __hip_atomic_fetch_and(mword, ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long old = __hip_atomic_fetch_and(mword, ~bit, MCPT_POOL_CLAIM_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
                 have = (old & bit) != 0ull;
                 k = kk;
                 cm = old & ~bit;
@@ -537,7 +555,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         if (have && c == C_INNER && nc == C_INNER) { keep = true; keep_k = k; nc = C_DEAD; }      // (not filed: it stays with this lane)
 #endif
         if (have && nc != C_DEAD)
-            __hip_atomic_fetch_or(&L.mask[(nc >> 1) * 64 + lane], 1ull << (32 * (nc & 1) + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&L.mask[(nc >> 1) * 64 + lane], 1ull << (32 * (nc & 1) + k), MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #undef MCPT_TOUCH
     junk += pf;

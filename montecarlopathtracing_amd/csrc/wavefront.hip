@@ -23,6 +23,9 @@ namespace mcpt {
                                3: 108.0, 4: 107.2, 5: 113.5, 6: 121.2; with the 4-wave trace engine: 3: 101.6, 4: 100.4 (cornell-box), equal within
                                0.3 % on veach-mis, the interior and the 10 M-triangle scene */
 #endif
+#ifndef MCPT_LOGIC_WAVES_FIRST
+#define MCPT_LOGIC_WAVES_FIRST MCPT_LOGIC_WAVES     /* ... its first pass (no resolve: fewer values alive) */
+#endif
 
 // ---------------------------------------------------------------------------------------------- layout helpers
 __device__ __forceinline__ V3 ldc(const double* __restrict__ a, long long cap, long long i)
@@ -63,7 +66,7 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfSta
 // ---------------------------------------------------------------------------------------------- logic kernel
 // One thread per path position of the previous iteration.  FIRST: positions enumerate (hit slot, k).
 template <bool FIRST>
-__global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a)
+__global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a)
 {
     const long long n_prev = (long long)a.counts_in->n_next * a.count_mul;
     if (!FIRST && n_prev <= (long long)a.finish_below) return;         // those paths went to k_wf_finish
@@ -211,6 +214,12 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         }
 
         // ---- shade vertex `depth` at position j (pathTracing.cpp:147-241; the pieces are in vertex.hpp)
+        // What is known goes out at once and the bounce is sampled before the lights (every uniform has its own counter: the order of
+        // evaluation is free): L, p and the sample id are stored before anything is computed, the incoming direction dies with
+        // bounce_sample -- the later passes' values that are alive at the same time, and with them the registers the compiler had to
+        // park in scratch memory (39 at 4 waves per SIMD), are what this order is about.
+        a.out.id[j] = id;
+        if (!FIRST) { stc(a.out.L, cap, j, L); stc(a.out.p, cap, j, p); }       // first pass: L = 0; p is the pixel's primary hit (a.hits)
         const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
         V3 pn = pn_first, kd = kd_first;
         if (!FIRST) vertex_surface(S, leaf, p, m, pn, kd);
@@ -220,6 +229,15 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
         if (FIRST) key.pixel = (uint32_t)pix_first;
         else { const int slot = a.first_slot + id / a.spp; key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); }
         key.sample = (uint32_t)(id % a.spp);
+
+        {
+            V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
+            const int btype = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
+            if (btype >= 0) { stc(a.out.bdir, cap, j, nd); ls.bounce++; }
+            a.out.btype[j] = btype;
+            if (folded) stc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
+            else { stc(a.out.w, cap, j, wgt); if (!FIRST) stc(a.out.T, cap, j, T); }
+        }
 
         int sample_mat = -1;
         for (int l = 0; l < nl; l++) {
@@ -232,16 +250,6 @@ __global__ void __launch_bounds__(256, MCPT_LOGIC_WAVES) k_wf_logic(DScene S, Wf
             } else ls.skipped++;
             a.out.expect[(long long)l * cap + j] = expect;
         }
-
-        if (!FIRST) stc(a.out.p, cap, j, p);             // first pass: the pixel's primary hit, read from a.hits where needed
-        V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
-        const int btype = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
-        if (btype >= 0) { stc(a.out.bdir, cap, j, nd); ls.bounce++; }
-        a.out.id[j] = id;
-        a.out.btype[j] = btype;
-        if (folded) stc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
-        else { stc(a.out.w, cap, j, wgt); if (!FIRST) stc(a.out.T, cap, j, T); }
-        if (!FIRST) stc(a.out.L, cap, j, L);
         MCPT_LSTAMP(2)
     }
 #ifdef MCPT_TRACE_DIAG
