@@ -140,6 +140,7 @@ struct mcpt_device {
         WfCounts* wf_counts = nullptr;                  // MCPT_WF_COUNT_SLOTS slots
         TraceQueue* queue = nullptr;                    // persistent trace kernels: chunk queue head + deferred-ray list
         long long* slow_list = nullptr;
+        char* path_area = nullptr;                      // records and exact-walk stacks of the pool form of the finishing pass (finish_pool_bytes)
         DCounters* ctr = nullptr;
         hipEvent_t done = nullptr;                      // recorded after the slot's last kernel of a frame
         bool used = false;
@@ -557,7 +558,7 @@ void mcpt_device_free(mcpt_device* d)
                     d->dirs, d->pixels};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& f : d->slot) {
-        void* q[] = {f.hits, f.rad, f.wf_ws, f.hit_slots, f.surf, f.alive_base, f.wf_counts, f.queue, f.slow_list, f.ctr};
+        void* q[] = {f.hits, f.rad, f.wf_ws, f.hit_slots, f.surf, f.alive_base, f.wf_counts, f.queue, f.slow_list, f.path_area, f.ctr};
         for (void* p : q) if (p) (void)hipFree(p);
         if (f.done) (void)hipEventDestroy(f.done);
     }
@@ -863,7 +864,13 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     d->cfg.trace_pool = trace_engine_for(t) == MCPT_ENGINE_POOL ? 1 : 0;
     // the pool engine keeps the stack entries of a ray beyond those it has in LDS in an area behind the deferred-ray list of the launch
     const size_t spill_bytes = d->cfg.trace_pool ? pool_spill_bytes(d->cfg.cus) : 0;
+    // ... and finishes a frame's last paths in path mode (MCPT_FINISH_ENGINE=lane: the one-lane-per-path kernel, for A/B runs)
+    d->cfg.finish_pool = d->cfg.trace_pool;
+    if (const char* e = std::getenv("MCPT_FINISH_ENGINE")) { if (std::strcmp(e, "lane") == 0) d->cfg.finish_pool = 0; }
+    const size_t path_bytes = d->cfg.finish_pool ? finish_pool_bytes(d->cfg.cus, int(s.lights.size())) : 0;     // (0: a path's rays do not fit a lane's slots)
+    if (!path_bytes) d->cfg.finish_pool = 0;
     for (auto& f : d->slot) {
+        if (path_bytes) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.path_area), path_bytes));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.ctr), sizeof(DCounters)));
         HIP_TRY(hipMemset(f.ctr, 0, sizeof(DCounters)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f.wf_counts), sizeof(WfCounts) * MCPT_WF_COUNT_SLOTS));
@@ -1217,7 +1224,7 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
                 HIP_TRY(hipStreamSynchronize(d->look_stream));
                 const unsigned int n_now = *d->h_look;
                 if (n_now <= a.finish_below) {
-                    if (n_now > 0) { launch_wf_finish(d->ds, a, (long long)n_now, st, d->cfg); HIP_TRY(hipGetLastError()); }
+                    if (n_now > 0) { launch_wf_finish(d->ds, a, (long long)n_now, st, d->cfg, f.path_area, f.slow_list, d->slow_cap); HIP_TRY(hipGetLastError()); }
                     n_upper = 0;
                     break;
                 }
@@ -1225,7 +1232,7 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
                 n_grid = double(n_now);
             } else if (a.finish_below) {
                 // few paths left (decided on the device from this pass's count): one lane per path runs them to the end
-                launch_wf_finish(d->ds, a, std::min<long long>(n_launch, (long long)a.finish_below), st, d->cfg);
+                launch_wf_finish(d->ds, a, std::min<long long>(n_launch, (long long)a.finish_below), st, d->cfg, f.path_area, f.slow_list, d->slow_cap);
                 HIP_TRY(hipGetLastError());
             }
             const long long n_trace = look ? (long long)n_grid : n_launch;

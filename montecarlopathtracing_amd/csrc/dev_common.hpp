@@ -26,6 +26,16 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk(a.y * b.z - b.y * a.
 __device__ __forceinline__ double norm(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 __device__ __forceinline__ V3 normalized(V3 a) { double d = norm(a); return mk(a.x / d, a.y / d, a.z / d); }
 
+// component-major SoA ([component][cap]: the wavefront path state, wavefront.hpp): element i of a 3-vector array
+__device__ __forceinline__ V3 ldc(const double* __restrict__ a, long long cap, long long i)
+{
+    return mk(a[i], a[cap + i], a[2 * cap + i]);
+}
+__device__ __forceinline__ void stc(double* __restrict__ a, long long cap, long long i, V3 v)
+{
+    a[i] = v.x; a[cap + i] = v.y; a[2 * cap + i] = v.z;
+}
+
 // dmin / dmax, sceneManagement.cpp:3-15 (if-chains with their NaN fall-through)
 __device__ __forceinline__ double dmin3(double p1, double p2, double p3)
 {

@@ -28,6 +28,7 @@ struct LaunchCfg {
     long long trace_block_rays = 2048;              // MCPT_TRACE_BLOCK_RAYS: a block of k_wf_trace is started per this many rays
     int min_chunk = 256, max_chunk = 2048;          // MCPT_TRACE_MIN_CHUNK / MAX_CHUNK: ray slots per queue claim
     int trace_pool = 0;                             // the pool engine (rays resident in LDS: k_wf_trace_pool, k_trace_pool) instead of the voting engine
+    int finish_pool = 0;                            // the finishing pass in its pool form (k_wf_finish_pool: paths resident with their rays)
 };
 bool pool_engine_available();                      // wavefront.hip: the current device can hold a workgroup of the pool engine
 bool pool_engine_available_closest();              // kernels.hip: ... of its closest-hit forms

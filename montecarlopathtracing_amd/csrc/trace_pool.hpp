@@ -21,10 +21,23 @@
 //     stack_cap goes to the deferred list (one-lane walk), like in the persistent engine.
 // The decisions are the persistent engine's, test for test (same cw_step, tri_pre_reject, tri_hit, ranking, own-box check at the end),
 // so results are bit-identical to it and to the reference-shaped walk.
+//
+// Path mode (template parameter PP with kPaths = true; what k_wf_finish_pool runs): the same workgroup also OWNS the paths its rays belong
+// to.  A lane's KT ray slots are dealt to KT / (lights + 1) path slots -- one slot per shadow ray and one for the bounce ray -- and a
+// fifth class, SHADE, takes a path whose rays have all come back: resolve the vertex (visibility -> direct light, bounce hit -> next
+// vertex), shade the next one with the logic kernel's own functions (vertex.hpp), write its rays straight into the path's ray slots
+// and file them under the node class; a path that ends hands its slot to the next path of the wavefront state (adoption: its pending
+// rays are read from the state k_wf_logic left).  No ray ever goes through memory, the result step neither fetches nor stores (it notes
+// leaf / material in the slot and clears the ray's bit in the lane's busy word; whoever clears the last bit of a path files it under
+// SHADE), and every path advances at its own pace: the one-lane-per-path finishing kernel this replaces ran 64 paths in lock-step, a
+// step as long as its slowest walk.
 #pragma once
 #include "trace_persistent.hpp"
+#include "vertex.hpp"
 
 namespace mcpt {
+
+struct NoPaths { static constexpr bool kPaths = false; };
 
 #ifndef MCPT_POOL_WAVES
 #define MCPT_POOL_WAVES 16
@@ -82,6 +95,9 @@ namespace mcpt {
 #ifndef MCPT_PW_FIN
 #define MCPT_PW_FIN 4
 #endif
+#ifndef MCPT_PW_SHADE
+#define MCPT_PW_SHADE 4             /* path mode: weight of the paths waiting for their next vertex */
+#endif
 
 struct alignas(16) PoolOxy { double ox, oy; };
 struct alignas(16) PoolOzDx { double oz, dx; };
@@ -105,10 +121,12 @@ struct PoolLds {
     int best_leaf[KT * 64];
     int spf[KT * 64];                       // stack entries (bits 0-7) | flags | leaf: number of triangles, exact class: survivors (bits 16-23)
     int stack[SCAP * KT * 64];              // [entry][k][lane]
-    unsigned long long mask[2 * 64];        // [2][lane]: class c in bits 32 (c & 1) .. + 31 of word c >> 1 (8 bytes per lane: no bank conflict)
+    unsigned long long mask[3 * 64];        // [3][lane]: class c in bits 32 (c & 1) .. + 31 of word c >> 1 (8 bytes per lane: no bank conflict); word 2: path mode
+    unsigned int busy[64];                  // path mode: bit k = ray slot k of this lane is still walking
     int tbl[NW * 64];                       // refill: rank among the fetched rays -> lane that holds it
     uint4 nodes[MCPT_POOL_CACHE_N ? MCPT_POOL_CACHE_N * 4 : 1];     // the top of the tree (trace_fast.hpp: NodeCache)
-    unsigned int live;                      // slots that may still carry a ray
+    unsigned int stat[8];                   // path mode: shade calls, shadow rays, bounce rays, shadow rays skipped, deepest vertex (flushed by the kernel)
+    unsigned int live;                      // slots that may still carry a ray (path mode: path slots that may still carry a path)
     unsigned int dry;                       // waves whose supply of source slots has run out
 };
 
@@ -121,13 +139,14 @@ __device__ __forceinline__ long long uni(long long v)
     return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
 }
 
-template <class Src, int NW, int KT, int SCAP>
+template <class Src, int NW, int KT, int SCAP, class PP = NoPaths>
 __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, TraceQueue* queue, long long* __restrict__ slow_list,
                                            unsigned int slow_cap, long long chunk, PoolLds<NW, KT, SCAP>& L, Work& w,
-                                           int* __restrict__ spill /* [block][MCPT_POOL_SPILL][KT * 64] stack entries beyond SCAP, or null */)
+                                           int* __restrict__ spill /* [block][MCPT_POOL_SPILL][KT * 64] stack entries beyond SCAP, or null */,
+                                           const PP& pp = PP())
 {
     static_assert(KT <= 32, "one 32-bit set per class");
-    enum { C_INNER = 0, C_LEAF = 1, C_EXACT = 2, C_FIN = 3, C_DEAD = 4 };
+    enum { C_INNER = 0, C_LEAF = 1, C_EXACT = 2, C_FIN = 3, C_SHADE = 4, C_DEAD = 5 };
     enum { F_FOUND = 256, F_AMBIG = 512, F_RAY = 1024 };
     const DFast& F = S.fast;
     const CwNode* __restrict__ nodes = F.cw;
@@ -150,17 +169,27 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     };
 
     // every slot starts in the finish class without a ray: the first steps of every wave are refills
-    for (int k = wave; k < KT; k += NW) L.spf[k * 64 + lane] = 0;
+    // (path mode: every path slot starts free in the SHADE class -- the first steps are adoptions -- and no ray slot is filed)
+    for (int k = wave; k < KT; k += NW) { L.spf[k * 64 + lane] = 0; if constexpr (PP::kPaths) L.q[k * 64 + lane] = 0u; }
     const NodeCache ncache = {L.nodes, F.cached < MCPT_POOL_CACHE_N ? F.cached : MCPT_POOL_CACHE_N};
     { const uint4* g = reinterpret_cast<const uint4*>(nodes); for (int i = threadIdx.x; i < ncache.n * 4; i += NW * 64) L.nodes[i] = g[i]; }
-    if (wave == 0) { L.mask[lane] = 0ull; L.mask[64 + lane] = ((1ull << KT) - 1ull) << 32; }       // (C_FIN: upper half of word 1)
-    if (threadIdx.x == 0) { L.live = KT * 64; L.dry = 0; }
+    // path mode: R ray slots per path (one per light and the bounce ray), NP path slots per lane
+    int R = 1, NP = KT;
+    if constexpr (PP::kPaths) { R = pp.nl + 1; NP = KT / R; }
+    if (wave == 0) {
+        L.mask[lane] = 0ull;
+        L.mask[64 + lane] = PP::kPaths ? 0ull : ((1ull << KT) - 1ull) << 32;        // (C_FIN: upper half of word 1)
+        L.mask[128 + lane] = PP::kPaths ? (1ull << NP) - 1ull : 0ull;               // (C_SHADE: lower half of word 2)
+        L.busy[lane] = 0u;
+    }
+    if (threadIdx.x == 0) { L.live = (PP::kPaths ? NP : KT) * 64; L.dry = 0; }
+    if (threadIdx.x < 8) L.stat[threadIdx.x] = 0u;
     __syncthreads();
 
     unsigned int c_nodes = 0, c_rays = 0, c_exact = 0;
 #ifdef MCPT_POOL_DEBUG
     unsigned long long d_used = 0, d_okc = 0, d_steps = 0, d_kill = 0, d_tickets = 0;
-    unsigned long long d_cs[4] = {0, 0, 0, 0}, d_cl[4] = {0, 0, 0, 0}, d_sleep = 0, d_miss = 0, d_want[4] = {0, 0, 0, 0};
+    unsigned long long d_cs[5] = {0, 0, 0, 0, 0}, d_cl[5] = {0, 0, 0, 0, 0}, d_sleep = 0, d_miss = 0, d_want[5] = {0, 0, 0, 0, 0};
 #endif
     long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk of source slots
     bool queue_empty = false;
@@ -222,9 +251,15 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         const int n_exact = __popcll(__ballot((unsigned int)m1 != 0u));
         // A wave's claim on source slots is private (a chunk per ticket): once the tickets are gone, a wave without a chunk leaves the
         // finish class to the waves that still have rays to hand out; a slot is retired only when every wave of the block is dry.
-        const bool fin_ok = !queue_empty || uni((int)__hip_atomic_load(&L.dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == NW;
+        const bool fin_ok = PP::kPaths || !queue_empty || uni((int)__hip_atomic_load(&L.dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == NW;
         const int n_fin = fin_ok ? __popcll(__ballot((m1 >> 32) != 0ull)) : 0;
-        if (!(n_inner | n_leaf | n_exact | n_fin)) {
+        unsigned long long m2 = 0ull;
+        int n_shade = 0;
+        if constexpr (PP::kPaths) {
+            m2 = __hip_atomic_load(&L.mask[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            n_shade = __popcll(__ballot(m2 != 0ull));
+        }
+        if (!(n_inner | n_leaf | n_exact | n_fin | n_shade)) {
             // (no lane keeps a slot here: n_inner counts them)
             if (uni((int)__hip_atomic_load(&L.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) break;
             __builtin_amdgcn_s_sleep(4);         // the other waves hold what is left
@@ -237,6 +272,8 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         if (MCPT_PW_EXACT * n_exact > best_score) { c = C_EXACT; best_score = MCPT_PW_EXACT * n_exact; }
         if (MCPT_PW_LEAF * n_leaf > best_score) { c = C_LEAF; best_score = MCPT_PW_LEAF * n_leaf; }
         if (MCPT_PW_INNER * n_inner > best_score) { c = C_INNER; best_score = MCPT_PW_INNER * n_inner; }
+        // (a waiting path keeps up to R ray slots idle: the SHADE class goes first on a tie)
+        if (PP::kPaths && MCPT_PW_SHADE * n_shade >= best_score && n_shade) { c = C_SHADE; best_score = MCPT_PW_SHADE * n_shade; }
 #if MCPT_POOL_PREF
         {
             const int s0 = MCPT_PW_INNER * n_inner * (pref == C_INNER ? 4 + MCPT_POOL_PREF : 4), s1 = MCPT_PW_LEAF * n_leaf * (pref == C_LEAF ? 4 + MCPT_POOL_PREF : 4);
@@ -259,7 +296,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         bool have = keep;
         int k = keep_k;
         keep = false;
-        unsigned long long cm = c < 2 ? m0 : m1;
+        unsigned long long cm = c < 2 ? m0 : (c < 4 ? m1 : m2);
         unsigned long long* const mword = &L.mask[(c >> 1) * 64 + lane];
         const int mshift = 32 * (c & 1);
 #if MCPT_POOL_GRAB
@@ -308,7 +345,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         if (!hv) continue;
         const int n_have = __popcll(hv);
 #ifdef MCPT_POOL_DEBUG
-        d_cs[c]++; d_cl[c] += n_have; d_want[c] += c == C_INNER ? n_inner : (c == C_LEAF ? n_leaf : (c == C_EXACT ? n_exact : n_fin));
+        d_cs[c]++; d_cl[c] += n_have; d_want[c] += c == C_INNER ? n_inner : (c == C_LEAF ? n_leaf : (c == C_EXACT ? n_exact : (c == C_FIN ? n_fin : n_shade)));
 #endif
         const int idx = k * 64 + lane;
         int nc = C_DEAD;
@@ -444,6 +481,224 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 }
                 else nc = pop_next(idx, k, spf);
                 if (nc == C_FIN) L.spf[idx] = spf & 0xffff;
+            }
+        } else if (PP::kPaths && c == C_FIN) {
+            if constexpr (PP::kPaths) {
+                // ---------------------------------------------------------------- path mode: the ray's answer stays in its slot
+                // (reference leaf in best_leaf, its material in cur; the ray itself stays where it is: the SHADE step forms the hit point from it)
+                if (have) {
+                    const int spf = L.spf[idx];
+                    const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
+                    Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
+                    bool found = (spf & F_FOUND) != 0;
+                    bool ambiguous = (spf & F_AMBIG) != 0;
+                    int leaf_ref = -1, mat = -1;
+                    if (found) {
+                        const V3 rc = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+                        const DTri* tr = tris + L.best_leaf[idx];
+                        if (!own_box_hit(tr, r, rc)) ambiguous = true;
+                        leaf_ref = tr->leaf; mat = tr->material;
+                    }
+                    if (ambiguous) {
+                        // rare (a leader whose own box fails, a walk past the stack, a ray the fast walk may not take): the one-lane exact
+                        // walk on the spot -- what the trace kernels leave to their deferred-ray pass
+                        Hit hh;
+                        Work w2 = {0, 0};
+                        const bool ok = fast_path_ok(F, r) ? trace_lane_fast(S, r, hh, w2, pp.lane_stack(wave, lane), 1) : trace_closest(S, r, hh, w2);
+                        w.nodes += w2.nodes; w.tris += w2.tris;
+                        found = ok; leaf_ref = ok ? hh.leaf : -1; mat = ok ? S.tris[hh.leaf].material : -1;
+                    }
+                    L.best_leaf[idx] = found ? leaf_ref : -1;
+                    L.cur[idx] = found ? mat : -1;
+                    // whoever clears the last busy bit of a path files the path (acquire + release: the other rays' answers, written by other
+                    // waves before they cleared theirs, are visible to the SHADE step this leads to)
+                    const unsigned int bit = 1u << k;
+                    const unsigned int old = __hip_atomic_fetch_and(&L.busy[lane], ~bit, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int pk = (int)(((float)k + 0.5f) * pp.inv_r);
+                    const unsigned int pm = ((1u << R) - 1u) << (pk * R);
+                    if (((old & ~bit) & pm) == 0u)
+                        __hip_atomic_fetch_or(&L.mask[128 + lane], 1ull << pk, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    nc = C_DEAD;                                        // the ray slot is idle until its path's next vertex
+                }
+            }
+        } else if (PP::kPaths) {
+            if constexpr (PP::kPaths) {
+                // ---------------------------------------------------------------- a path whose rays are all back, or a free path slot
+                // k = path slot; its ray slots are k * R + l, l = R - 1 for the bounce ray.  The arithmetic is k_wf_logic's / k_wf_finish's
+                // (vertex.hpp), operation for operation; a path's record lives in this block's part of a global area, [field][path slot][lane].
+                const WfArgs& a = pp.a;
+                const int nl = pp.nl;
+                const bool folded = nl == 1;                             // see k_wf_logic
+                const long long cap = a.cap;
+                const int s0 = k * R;
+                const size_t plane = (size_t)pp.npc * 64;
+                double* __restrict__ rd = pp.recd + (size_t)blockIdx.x * (size_t)(9 + 3 * nl) * plane + (size_t)k * 64 + lane;
+                int* __restrict__ ri = pp.reci + (size_t)blockIdx.x * (size_t)(3 + nl) * plane + (size_t)k * 64 + lane;
+                enum { P_FREE = 0, P_ADOPTED = 1, P_VERTEX = 2 };
+                enum { RI_ID = 0, RI_DEPTH = 1, RI_BT = 2, RI_EXPECT = 3 };
+                enum { RD_T = 0, RD_L = 3, RD_W = 6, RD_C = 9 };
+                auto ldp = [&](int f) __attribute__((always_inline)) { return mk(rd[(size_t)f * plane], rd[(size_t)(f + 1) * plane], rd[(size_t)(f + 2) * plane]); };
+                auto stp = [&](int f, const V3& v) __attribute__((always_inline)) { rd[(size_t)f * plane] = v.x; rd[(size_t)(f + 1) * plane] = v.y; rd[(size_t)(f + 2) * plane] = v.z; };
+                int mode = have ? (int)L.q[s0 * 64 + lane] : P_FREE;
+                int id = 0, leaf = -1, in_type = RT_TRANSMISSION;
+                uint32_t depth = 0;
+                V3 T = mk(1, 1, 1), Lr = mk(0, 0, 0), p = mk(0, 0, 0), dir = mk(0, 0, 0);
+                bool at_vertex = false;
+                // ---- resolve the vertex whose rays have come back (pathTracing.cpp:213-231, 244-261)
+                if (have && mode != P_FREE) {
+                    id = ri[RI_ID * plane]; depth = (uint32_t)ri[RI_DEPTH * plane];
+                    const int bt = ri[RI_BT * plane];
+                    T = ldp(RD_T); Lr = ldp(RD_L);
+                    V3 L_dir = mk(0, 0, 0);
+                    for (int l = 0; l < nl; l++) {
+                        const int expect = ri[(size_t)(RI_EXPECT + l) * plane];
+                        if (expect == -2) continue;
+                        const V3 cc = ldp(RD_C + 3 * l);
+                        const bool vis = L.cur[(s0 + l) * 64 + lane] == expect;
+                        L_dir.x += vis ? cc.x : cc.x * 0.0;
+                        L_dir.y += vis ? cc.y : cc.y * 0.0;
+                        L_dir.z += vis ? cc.z : cc.z * 0.0;
+                    }
+                    if (mode == P_ADOPTED && folded) Lr = Lr + L_dir;            // its c was stored as T * c
+                    else Lr = Lr + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
+                    const int bidx = (s0 + nl) * 64 + lane;
+                    const int hl = bt >= 0 ? L.best_leaf[bidx] : -1;
+                    if (hl >= 0) {
+                        // an adopted path with one light already holds the throughput after its bounce
+                        if (!(mode == P_ADOPTED && folded)) { const V3 wgt = ldp(RD_W); T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR); }
+                        // the hit point: the first two lines of the reference's triangle test on the ray that is still in its slot
+                        const PoolOxy b0 = L.oxy[bidx]; const PoolOzDx b1 = L.ozdx[bidx]; const PoolDyz b2 = L.dyz[bidx];
+                        const V3 ro = mk(b0.ox, b0.oy, b1.oz), bd = mk(b1.dx, b2.dy, b2.dz);
+                        const DTri* tr = S.tris + hl;
+                        const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
+                        const double t = dot(v1 - ro, n) / dot(n, bd);
+                        p = ro + bd * t; dir = neg(bd); in_type = bt & 7; depth++; leaf = hl;
+                        at_vertex = true;
+                    }
+                }
+                bool ended = have && mode != P_FREE && !at_vertex;       // no bounce ray, or it left the scene
+                // ---- the next vertex: emitter test, surface (pathTracing.cpp:141-160)
+                const DMaterial* m = nullptr;
+                V3 pn = mk(0, 0, 0), kd = mk(0, 0, 0);
+                const int n_shades = __popcll(__ballot(at_vertex));
+                const unsigned int deepest = wave_max(at_vertex ? depth : 0u);
+                if (at_vertex) {
+                    m = S.materials + S.tris[leaf].material;
+                    if (m->light >= 0) {
+                        const V3 rad = ld3(S.lights[m->light].radiance);
+                        if (depth == 0) Lr = rad;
+                        else if (in_type != RT_DIFFUSE) Lr = Lr + mk(T.x * rad.x, T.y * rad.y, T.z * rad.z);
+                        ended = true; at_vertex = false;
+                    } else vertex_surface(S, leaf, p, m, pn, kd);
+                }
+                if (ended) { a.rad[(size_t)id * 3] = Lr.x; a.rad[(size_t)id * 3 + 1] = Lr.y; a.rad[(size_t)id * 3 + 2] = Lr.z; mode = P_FREE; }
+                // ---- rays go straight into the path's slots
+                unsigned int nb_inner = 0u, nb_fin = 0u;
+                auto emit = [&](int sk, const V3& o, const V3& d) __attribute__((always_inline)) {
+                    const int i2 = sk * 64 + lane;
+                    Ray r; r.o = o; r.d = d;
+                    const bool okf = fast_path_ok(F, r);
+                    const V3 rcp = mk(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+                    PoolOxy b0; b0.ox = o.x; b0.oy = o.y;
+                    PoolOzDx b1; b1.oz = o.z; b1.dx = d.x;
+                    PoolDyz b2; b2.dy = d.y; b2.dz = d.z;
+                    PoolRcp b4; b4.rx = (float)rcp.x; b4.ry = (float)rcp.y; b4.rz = (float)rcp.z; b4.limit = __builtin_inff();
+                    L.oxy[i2] = b0; L.ozdx[i2] = b1; L.dyz[i2] = b2; L.rcp[i2] = b4;
+                    L.best_t[i2] = 0;
+                    L.cur[i2] = 0; L.best_leaf[i2] = -1; L.spf[i2] = okf ? F_RAY : (F_RAY | F_AMBIG);
+                    if (okf) nb_inner |= 1u << sk; else nb_fin |= 1u << sk;
+                };
+                int n_shadow = 0, n_skipped = 0, n_bounce = 0;
+                if (at_vertex) {
+                    RngKey key;
+                    key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
+                    const int slot = a.first_slot + id / a.spp;
+                    key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); key.sample = (uint32_t)(id % a.spp);
+                    int sample_mat = -1;
+                    for (int l = 0; l < nl; l++) {
+                        V3 direction, cc;
+                        const int expect = light_sample(S, key, depth, l, p, pn, kd, sample_mat, direction, cc);
+                        ri[(size_t)(RI_EXPECT + l) * plane] = expect;
+                        if (expect != -2) { stp(RD_C + 3 * l, cc); emit(s0 + l, p + direction * 0.01, direction); n_shadow++; }
+                        else n_skipped++;
+                    }
+                    V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
+                    const int bt = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
+                    ri[RI_BT * plane] = bt;
+                    if (bt >= 0) { stp(RD_W, wgt); emit(s0 + nl, (bt & MCPT_BT_NO_OFFSET) ? p : p + nd * 0.01, nd); n_bounce++; }
+                    ri[RI_DEPTH * plane] = (int)depth;
+                    stp(RD_T, T); stp(RD_L, Lr);
+                    mode = P_VERTEX;
+                }
+                // ---- a free path slot adopts the next path of the wavefront state (its rays are pending there: k_wf_logic wrote them)
+                const bool want_path = have && mode == P_FREE;
+                const unsigned long long wb = __ballot(want_path);
+                bool dead = false;
+                if (wb) {
+                    long long mine = pp.n;
+                    if (!queue_empty) {
+                        const unsigned int want = (unsigned int)__popcll(wb);
+                        unsigned int got = 0;
+                        if (lane == 0) got = atomicAdd(&a.counts->pad[0], want);
+                        got = (unsigned int)uni((int)got);
+                        if ((long long)got + want >= pp.n) queue_empty = true;
+                        mine = (long long)got + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(wb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wb, 0u));
+                    }
+                    if (want_path) {
+                        if (mine < pp.n) {
+                            const long long j = mine;
+                            id = a.out.id[j];
+                            depth = (uint32_t)a.depth;
+                            T = mk(1, 1, 1); Lr = mk(0, 0, 0);
+                            if (a.depth > 0 || folded) T = ldc(a.out.T, cap, j);
+                            if (a.depth > 0) Lr = ldc(a.out.L, cap, j);
+                            if (a.depth == 0) { const PrimaryHit* ph = a.hits + (a.first_slot + id / a.spp); p = mk(ph->p[0], ph->p[1], ph->p[2]); }
+                            else p = ldc(a.out.p, cap, j);
+                            for (int l = 0; l < nl; l++) {
+                                const int expect = a.out.expect[(long long)l * cap + j];
+                                ri[(size_t)(RI_EXPECT + l) * plane] = expect;
+                                if (expect != -2) {
+                                    const V3 cc = ldc(a.out.c + (long long)l * 3 * cap, cap, j), d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j);
+                                    stp(RD_C + 3 * l, cc); emit(s0 + l, p + d * 0.01, d);
+                                }
+                            }
+                            const int bt = a.out.btype[j];
+                            ri[RI_BT * plane] = bt;
+                            if (bt >= 0) {
+                                const V3 bd = ldc(a.out.bdir, cap, j);
+                                if (!folded) stp(RD_W, ldc(a.out.w, cap, j));
+                                emit(s0 + nl, (bt & MCPT_BT_NO_OFFSET) ? p : p + bd * 0.01, bd);
+                            }
+                            ri[RI_ID * plane] = id; ri[RI_DEPTH * plane] = (int)depth;
+                            stp(RD_T, T); stp(RD_L, Lr);
+                            mode = P_ADOPTED;
+                        } else dead = true;                                 // no path left, in any block
+                    }
+                }
+                if (have) {
+                    L.q[s0 * 64 + lane] = (unsigned int)mode;
+                    const unsigned int nb = nb_inner | nb_fin;
+                    // (the busy bits before the filing: a ray's result step, in another wave, clears its bit)
+                    if (nb) __hip_atomic_fetch_or(&L.busy[lane], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (nb_inner) __hip_atomic_fetch_or(&L.mask[lane], (unsigned long long)nb_inner, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (nb_fin) __hip_atomic_fetch_or(&L.mask[64 + lane], (unsigned long long)nb_fin << 32, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // a path without a ray in flight (nothing to trace at its vertex, or adopted without rays) is resolved by the next step;
+                    // a free slot that found no path is retired
+                    nc = (mode != P_FREE && !nb) ? C_SHADE : C_DEAD;
+                    w.rays += (unsigned int)__popc(nb);
+                }
+                const int n_dead = __popcll(__ballot(have && dead));
+                if (n_dead && lane == 0) __hip_atomic_fetch_sub(&L.live, (unsigned int)n_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // the logic kernel's counters, once per step
+                const unsigned int t_sh = (unsigned int)wave_sum((unsigned long long)n_shadow), t_sk = (unsigned int)wave_sum((unsigned long long)n_skipped),
+                                   t_bo = (unsigned int)wave_sum((unsigned long long)n_bounce);
+                if (lane == 0) {
+                    if (n_shades) atomicAdd(&L.stat[0], (unsigned int)n_shades);
+                    if (t_sh) atomicAdd(&L.stat[1], t_sh);
+                    if (t_bo) atomicAdd(&L.stat[2], t_bo);
+                    if (t_sk) atomicAdd(&L.stat[3], t_sk);
+                    if (deepest) atomicMax(&L.stat[4], deepest);
+                }
             }
         } else {
             // ---------------------------------------------------------------- results out, new rays in

@@ -1,4 +1,5 @@
-// Wavefront integrator kernels (see wavefront.hpp).  -ffp-contract=off.
+// Wavefront integrator, trace side: the closest-hit launches of an iteration (see wavefront.hpp; the logic and finishing kernels are in
+// wavefront_logic.hip, which is compiled with other code-generation options: Makefile).  -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -12,31 +13,11 @@
 #include "trace_pool.hpp"
 #include "vertex.hpp"
 #include "wavefront.hpp"
+#include "wf_ray_source.hpp"
 
 namespace mcpt {
 
-#ifndef MCPT_FINISH_WAVES
-#define MCPT_FINISH_WAVES 2  /* blocks of the finishing kernel per CU the compiler plans for: 2 = 256 registers per lane (76 bytes of them in scratch memory), 1 = 512 */
-#endif
-#ifndef MCPT_LOGIC_WAVES
-#define MCPT_LOGIC_WAVES 4   /* waves per SIMD the logic kernel is compiled for: 128 VGPRs, 20 / 40 spilled registers.  Round 1 (ms per frame): 2: 111.5,
-                               3: 108.0, 4: 107.2, 5: 113.5, 6: 121.2; with the 4-wave trace engine: 3: 101.6, 4: 100.4 (cornell-box), equal within
-                               0.3 % on veach-mis, the interior and the 10 M-triangle scene */
-#endif
-#ifndef MCPT_LOGIC_WAVES_FIRST
-#define MCPT_LOGIC_WAVES_FIRST MCPT_LOGIC_WAVES     /* ... its first pass (no resolve: fewer values alive) */
-#endif
-
-// ---------------------------------------------------------------------------------------------- layout helpers
-__device__ __forceinline__ V3 ldc(const double* __restrict__ a, long long cap, long long i)
-{
-    return mk(a[i], a[cap + i], a[2 * cap + i]);
-}
-__device__ __forceinline__ void stc(double* __restrict__ a, long long cap, long long i, V3 v)
-{
-    a[i] = v.x; a[cap + i] = v.y; a[2 * cap + i] = v.z;
-}
-
+// ---------------------------------------------------------------------------------------------- layout helpers (ldc / stc: dev_common.hpp)
 size_t wf_bytes_per_path(int nl)
 {
     const size_t state = 4 + (6 + 3 * nl + (nl == 1 ? 3 : 6)) * 8 + nl * 4 + 4 + nl * 4 + 4 + 3 * 8;   // WfState (no w with one light)
@@ -63,247 +44,7 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfSta
     return p <= end;
 }
 
-// ---------------------------------------------------------------------------------------------- logic kernel
-// One thread per path position of the previous iteration.  FIRST: positions enumerate (hit slot, k).
-template <bool FIRST>
-__global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a)
-{
-    const long long n_prev = (long long)a.counts_in->n_next * a.count_mul;
-    if (!FIRST && n_prev <= (long long)a.finish_below) return;         // those paths went to k_wf_finish
-    // (two sets, used in turn: the values of one block iteration are still being read by its slower waves while the faster ones
-    // write the next iteration's -- with one set that took a third barrier per iteration)
-    __shared__ unsigned int wave_tot[2][4];
-    __shared__ unsigned int block_base[2];
-    int turn = 0;
-    const long long cap = a.cap;
-    const int nl = a.nl;
-    // One light (the usual scene): T * c and T * w / P_RR are formed when the vertex is shaded instead of when it is resolved --
-    // the same products, one pass earlier -- so the bounce weight never goes through memory.
-    const bool folded = nl == 1;
-    const uint32_t depth = (uint32_t)a.depth;           // depth of the vertex shaded in this pass
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    LaneStats ls;
-#ifdef MCPT_TRACE_DIAG
-    unsigned long long dg[4] = {0, 0, 0, 0};
-#define MCPT_LSTAMP(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); dg[k] += tn - tl; tl = tn; }
-#else
-#define MCPT_LSTAMP(k)
-#endif
-#ifndef MCPT_FIRST_COMPACT
-    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) a.counts->n_next = a.counts_in->pad[2] * (unsigned int)a.spp;   // shaded pixels x samples
-#endif
-    const long long n_round = (n_prev + 255) / 256 * 256;
-    for (long long base = (long long)blockIdx.x * 256; base < n_round; base += (long long)gridDim.x * 256) {
-#ifdef MCPT_TRACE_DIAG
-        unsigned long long tl = __builtin_amdgcn_s_memtime();
-#endif
-        const long long i = base + threadIdx.x;
-        bool alive = false;
-        long long first_pos = 0;
-        int id = 0, leaf = -1, in_type = RT_TRANSMISSION, mat_first = 0, pix_first = 0;
-        V3 p = mk(0, 0, 0), dir = mk(0, 0, 0), T = mk(1, 1, 1), L = mk(0, 0, 0), pn_first = mk(0, 0, 0), kd_first = mk(0, 0, 0);
-        if (i < n_prev) {
-            bool have_vertex;
-            if constexpr (FIRST) {
-                const PrimarySurface* ps = a.surf + i / a.spp;          // the same record for all samples of a pixel
-                const int k = (int)(i % a.spp);
-                // Path positions in exact slot order trace measurably slower on a rank's share of a frame, so the pixels are shuffled
-                // within windows of 2^MCPT_SHUFFLE_LOG2 (an odd multiplier modulo a power of two is a bijection) -- close to the order
-                // the block-wise compaction used to leave.  One eighth of the frame, ms per frame by window: none (slot order) 18.8,
-                // 2^7 17.3, 2^10 16.5, 2^12 18.0, 2^14 18.7, 2^16 18.8; the whole frame is within 0.5 % for all of them.
-                unsigned int an = a.alive_base[(i / a.spp) >> 6] + (unsigned int)ps->alive_index;
-                const unsigned int n_alive = a.counts_in->pad[2];
-#ifndef MCPT_SHUFFLE_LOG2
-#define MCPT_SHUFFLE_LOG2 10
-#endif
-                constexpr unsigned int kWin = (1u << MCPT_SHUFFLE_LOG2) - 1u;
-                if ((an | kWin) < n_alive) an = (an & ~kWin) | ((an & kWin) * 40503u & kWin);      // (not in the last, partial window)
-                first_pos = (long long)an * a.spp + k;
-                id = (ps->slot - a.first_slot) * a.spp + k;
-                leaf = ps->leaf; mat_first = ps->material; pix_first = ps->pixel;
-                p = ld3(ps->p); dir = ld3(ps->dir); pn_first = ld3(ps->pn); kd_first = ld3(ps->kd);
-                have_vertex = true;
-                ls.samples = 1;
-            } else {
-                // ---- resolve vertex depth-1 (pathTracing.cpp:213-231, 244-261)
-                // Every word of the path is requested before any is looked at (what a dead path or an unused shadow slot
-                // holds is stale but harmless): one memory latency per pass instead of a chain of three.
-                id = a.in.id[i];
-                const int bt = a.in.btype[i];
-                const int hl = a.in.hit_leaf[i];
-                // folded (one light): in.T already is the throughput after the bounce and in.c is T * c (see the stores below)
-                if (depth > 1 || folded) T = ldc(a.in.T, cap, i);
-                if (depth > 1) L = ldc(a.in.L, cap, i);
-                V3 wgt = mk(1, 1, 1);
-                if (!folded) wgt = ldc(a.in.w, cap, i);
-                const V3 bd = ldc(a.in.bdir, cap, i);
-                // the vertex the bounce ray left from: the pixel's primary hit after the first pass, in.p afterwards
-                V3 pv;
-                if (depth == 1) { const PrimaryHit* ph = a.hits + (a.first_slot + id / a.spp); pv = mk(ph->p[0], ph->p[1], ph->p[2]); }
-                else pv = ldc(a.in.p, cap, i);
-                V3 L_dir = mk(0, 0, 0);
-                for (int l = 0; l < nl; l++) {
-                    const int expect = a.in.expect[(long long)l * cap + i];
-                    const int hm = a.in.hit_mat[(long long)l * cap + i];
-                    const V3 c = ldc(a.in.c + (long long)l * 3 * cap, cap, i);
-                    if (expect == -2) continue;
-                    const bool vis = hm == expect;
-                    L_dir.x += vis ? c.x : c.x * 0.0;
-                    L_dir.y += vis ? c.y : c.y * 0.0;
-                    L_dir.z += vis ? c.z : c.z * 0.0;
-                }
-                have_vertex = bt >= 0 && hl >= 0;
-                if (folded) {
-                    L = L + L_dir;
-                } else {
-                    L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
-                    if (have_vertex) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
-                }
-                if (have_vertex) {
-                    // the hit point of the bounce ray, as the reference's test formed it when the trace kernel accepted the triangle
-                    // (sceneManagement.cpp:318-320: t = ((v1 - o) . n) / (n . d), p = o + d t; same operands, same operations)
-                    const V3 ro = (bt & MCPT_BT_NO_OFFSET) ? pv : pv + bd * 0.01;
-                    const DTri* tr = S.tris + hl;
-                    const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
-                    const double t = dot(v1 - ro, n) / dot(n, bd);
-                    leaf = hl; p = ro + bd * t; dir = neg(bd); in_type = bt & 7;
-                }
-            }
-            if (have_vertex) {
-                ls.shades++;
-                if (depth > ls.depth) ls.depth = depth;
-                const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
-                if (m->light >= 0) {                                             // emitter: pathTracing.cpp:141-144
-                    const V3 rad = ld3(S.lights[m->light].radiance);
-                    if (FIRST) L = rad;
-                    else if (in_type != RT_DIFFUSE) L = L + mk(T.x * rad.x, T.y * rad.y, T.z * rad.z);
-                } else alive = true;
-            }
-            if (!alive) { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; }
-        }
-        MCPT_LSTAMP(0)
-        // ---- compaction.  First pass: none -- a pixel's samples live or die together, so k_primary_surface has numbered the shaded
-        // pixels and sample k of pixel number n sits at n * spp + k (no ballot, no atomic, no barrier).  Later passes: wave ballot +
-        // prefix, one atomic per block.
-        long long j;
-#ifndef MCPT_FIRST_COMPACT
-        if constexpr (FIRST) {
-            MCPT_LSTAMP(1)
-            if (!alive) continue;
-            j = first_pos;
-        } else
-#endif
-        {
-        const unsigned long long bal = __ballot(alive);
-        const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
-        turn ^= 1;
-        if (lane == 0) wave_tot[turn][wv] = (unsigned int)__popcll(bal);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int tot = wave_tot[turn][0] + wave_tot[turn][1] + wave_tot[turn][2] + wave_tot[turn][3];
-            // (one atomic per 256 paths on one word: with the word sharded 16 ways this kernel's first pass takes 6.0 instead of 6.5 ms --
-            // the counter is not its floor)
-            block_base[turn] = tot ? atomicAdd(&a.counts->n_next, tot) : 0u;
-        }
-        __syncthreads();
-        unsigned int off = block_base[turn] + before;
-        for (int q = 0; q < wv; q++) off += wave_tot[turn][q];
-        MCPT_LSTAMP(1)
-        if (!alive) continue;
-        j = off;
-        }
-
-        // ---- shade vertex `depth` at position j (pathTracing.cpp:147-241; the pieces are in vertex.hpp)
-        // What is known goes out at once and the bounce is sampled before the lights (every uniform has its own counter: the order of
-        // evaluation is free): L, p and the sample id are stored before anything is computed, the incoming direction dies with
-        // bounce_sample -- the later passes' values that are alive at the same time, and with them the registers the compiler had to
-        // park in scratch memory (39 at 4 waves per SIMD), are what this order is about.
-        a.out.id[j] = id;
-        if (!FIRST) { stc(a.out.L, cap, j, L); stc(a.out.p, cap, j, p); }       // first pass: L = 0; p is the pixel's primary hit (a.hits)
-        const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
-        V3 pn = pn_first, kd = kd_first;
-        if (!FIRST) vertex_surface(S, leaf, p, m, pn, kd);
-
-        RngKey key;
-        key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
-        if (FIRST) key.pixel = (uint32_t)pix_first;
-        else { const int slot = a.first_slot + id / a.spp; key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); }
-        key.sample = (uint32_t)(id % a.spp);
-
-        {
-            V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
-            const int btype = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
-            if (btype >= 0) { stc(a.out.bdir, cap, j, nd); ls.bounce++; }
-            a.out.btype[j] = btype;
-            if (folded) stc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
-            else { stc(a.out.w, cap, j, wgt); if (!FIRST) stc(a.out.T, cap, j, T); }
-        }
-
-        int sample_mat = -1;
-        for (int l = 0; l < nl; l++) {
-            V3 direction, c;
-            const int expect = light_sample(S, key, depth, l, p, pn, kd, sample_mat, direction, c);
-            if (expect != -2) {
-                stc(a.out.c + (long long)l * 3 * cap, cap, j, folded ? mk(T.x * c.x, T.y * c.y, T.z * c.z) : c);
-                stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);       // origin p + direction * 0.01: WfRaySource
-                ls.shadow++;
-            } else ls.skipped++;
-            a.out.expect[(long long)l * cap + j] = expect;
-        }
-        MCPT_LSTAMP(2)
-    }
-#ifdef MCPT_TRACE_DIAG
-    if ((threadIdx.x & 63) == 0 && a.ctr) { for (int k = 0; k < 3; k++) atomicAdd(&a.ctr->pad[16 + k], dg[k]); atomicAdd(&a.ctr->pad[19], 1ull); }
-#endif
-    flush_stats(a.ctr, ls);
-}
-
 // ---------------------------------------------------------------------------------------------- trace kernels
-// ray slot q = l*n_paths + j, l in [0, nl] (l == nl: the bounce ray of path j)
-struct WfRaySource {
-    static constexpr bool kWantsPoint = false;      // results are a leaf or a material: the hit point is formed again by the next logic pass
-    WfArgs a;
-    long long n_paths;
-    __device__ __forceinline__ long long total() const { return n_paths * (a.nl + 1); }
-    // (l, j) of slot q without a 64-bit division: nl is small
-    __device__ __forceinline__ void split(long long q, int& l, long long& j) const
-    {
-        l = 0; j = q;
-        while (j >= n_paths) { j -= n_paths; l++; }
-    }
-    // the vertex the rays of path j leave from: after the first pass every sample of a pixel still sits on its primary hit
-    __device__ __forceinline__ V3 vertex(long long j) const
-    {
-        if (a.depth == 0) {
-            const PrimaryHit* ph = a.hits + (a.first_slot + a.out.id[j] / a.spp);
-            return mk(ph->p[0], ph->p[1], ph->p[2]);
-        }
-        return ldc(a.out.p, a.cap, j);
-    }
-    __device__ __forceinline__ bool fetch(long long q, Ray& r) const
-    {
-        int l; long long j;
-        split(q, l, j);
-        // branch-free: the ray words are loaded whether or not the slot is in use, so nothing waits on the flag
-        const bool bounce = l == a.nl;
-        const int flag = bounce ? a.out.btype[j] : a.out.expect[(long long)l * a.cap + j];
-        const V3 p = vertex(j);
-        r.d = ldc(bounce ? a.out.bdir : a.rays.d + (long long)l * 3 * a.cap, a.cap, j);
-        r.o = (bounce && (flag & MCPT_BT_NO_OFFSET)) ? p : p + r.d * 0.01;
-        return bounce ? flag >= 0 : flag != -2;
-    }
-    __device__ __forceinline__ void store(long long q, bool ok, const Hit& h) const
-    {
-        int l; long long j;
-        split(q, l, j);
-        if (l == a.nl) {
-            a.out.hit_leaf[j] = ok ? h.leaf : -1;
-        } else {
-            // (the persistent engine hands the material over with the leaf: one dependent fetch less per shadow ray in its store batch)
-            a.out.hit_mat[(long long)l * a.cap + j] = ok ? (h.mat >= 0 ? h.mat : a.tris[h.leaf].material) : -1;
-        }
-    }
-};
 
 // persistent fast walk
 __device__ __forceinline__ long long wf_chunk(long long total, int min_chunk, int max_chunk)
@@ -406,292 +147,12 @@ __global__ void __launch_bounds__(256) k_wf_trace_reference(DScene S, WfArgs a)
     flush_stats(a.ctr, ls);
 }
 
-// ---------------------------------------------------------------------------------------------- finishing pass
-// When few paths are left, a launch pair per bounce costs more than the paths: every launch starts with cold caches and runs at
-// memory latency.  One persistent launch takes over the state logic(depth) has just written (its rays not yet traced) and runs
-// every remaining path to its end.  A wave advances its 64 paths one vertex per iteration, in step: trace the shadow rays,
-// resolve, trace the bounce ray, shade the next vertex (vertex.hpp: the arithmetic of k_wf_logic).  Lanes whose path has ended
-// take the next unclaimed path (one atomic per refill on the pass's own count slot), so a wave is as long as its share of
-// the work, not as its longest path.  A lane that has just adopted a path finds the rays of its first step in the wavefront
-// state instead of computing them; from the second step on everything lives in registers.
-__global__ void __launch_bounds__(256, MCPT_FINISH_WAVES) k_wf_finish(DScene S, WfArgs a)
-{
-    __shared__ int lds_stack[MCPT_FAST_STACK * 256];
-    const long long n = a.counts->n_next;
-    if (n == 0 || n > (long long)a.finish_below) return;               // nothing left, or still wavefront work
-    const long long cap = a.cap;
-    const int nl = a.nl;
-    const bool folded = nl == 1;                                       // see k_wf_logic
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    LaneStats ls;
-    Work w = {0, 0};
-    int* stack = lds_stack + threadIdx.x;
-    WfRaySource src; src.a = a; src.n_paths = n;
-    bool queue_empty = false;
-
-    enum { M_IDLE = 0, M_ADOPTED = 1, M_VERTEX = 2 };
-#ifdef MCPT_TRACE_DIAG
-    const unsigned long long fin_t0 = __builtin_amdgcn_s_memtime();
-    unsigned long long fin_iters = 0, fin_t_trace = 0;
-#endif
-    int mode = M_IDLE;
-    long long j = 0;                    // M_ADOPTED: position in the wavefront state
-    int id = 0, leaf = -1, in_type = RT_TRANSMISSION;
-    uint32_t depth = 0;                 // M_ADOPTED: vertex whose rays are pending; M_VERTEX: vertex about to be shaded
-    V3 T = mk(1, 1, 1), L = mk(0, 0, 0), dir = mk(0, 0, 0), p = mk(0, 0, 0);
-    RngKey key;
-    key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32); key.pixel = 0; key.sample = 0;
-
-    for (;;) {
-        // ---- idle lanes adopt the next paths
-        const unsigned long long idle = __ballot(mode == M_IDLE);
-        if (idle && !queue_empty && (__popcll(idle) >= 16 || idle == ~0ull)) {
-            const unsigned int want = (unsigned int)__popcll(idle);
-            unsigned int got = 0;
-            if (lane == 0) got = atomicAdd(&a.counts->pad[0], want);
-            got = __shfl(got, 0, 64);
-            if ((long long)got + want >= n) queue_empty = true;
-            const long long mine = (long long)got + __popcll(idle & lt_mask);
-            if (mode == M_IDLE && mine < n) {
-                mode = M_ADOPTED; j = mine;
-                id = a.out.id[j];
-                depth = (uint32_t)a.depth;
-                T = mk(1, 1, 1); L = mk(0, 0, 0);
-                if (a.depth > 0 || folded) T = ldc(a.out.T, cap, j);
-                if (a.depth > 0) L = ldc(a.out.L, cap, j);
-                p = src.vertex(j);
-                const int slot = a.first_slot + id / a.spp;
-                key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); key.sample = (uint32_t)(id % a.spp);
-            }
-        }
-        if (!__ballot(mode != M_IDLE)) {
-            if (queue_empty) break;
-            continue;
-        }
-
-        // ---- lanes at a vertex: emitter test, surface (pathTracing.cpp:141-160)
-        const DMaterial* m = nullptr;
-        V3 pn = mk(0, 0, 0), kd = mk(0, 0, 0);
-        bool ended = false;
-        if (mode == M_VERTEX) {
-            ls.shades++;
-            if (depth > ls.depth) ls.depth = depth;
-            m = S.materials + S.tris[leaf].material;
-            if (m->light >= 0) {
-                const V3 rad = ld3(S.lights[m->light].radiance);
-                if (depth == 0) L = rad;
-                else if (in_type != RT_DIFFUSE) L = L + mk(T.x * rad.x, T.y * rad.y, T.z * rad.z);
-                ended = true;
-            } else vertex_surface(S, leaf, p, m, pn, kd);
-        }
-
-        // ---- the rays of this step: one shadow ray per light and the bounce ray (Russian roulette + nextRay, or the stored ones)
-        V3 L_dir = mk(0, 0, 0);
-        int sample_mat = -1, expect0 = -2;
-        V3 c0 = mk(0, 0, 0);
-        Ray rs; rs.o = p; rs.d = mk(1, 1, 1);
-        for (int l = 0; l < nl; l++) {
-            int expect = -2;
-            V3 c = mk(0, 0, 0);
-            Ray r; r.o = p; r.d = mk(1, 1, 1);
-            if (mode == M_VERTEX && !ended) {
-                expect = light_sample(S, key, depth, l, p, pn, kd, sample_mat, r.d, c);
-                if (expect != -2) ls.shadow++; else ls.skipped++;
-            } else if (mode == M_ADOPTED) {
-                expect = a.out.expect[(long long)l * cap + j];
-                if (expect != -2) { c = ldc(a.out.c + (long long)l * 3 * cap, cap, j); r.d = ldc(a.rays.d + (long long)l * 3 * cap, cap, j); }
-            }
-            if (expect != -2) r.o = p + r.d * 0.01;
-            if (nl == 1) { expect0 = expect; c0 = c; rs = r; break; }       // traced below, together with the bounce ray
-            if (expect != -2) {
-                Hit h;
-                const bool ok = trace_lane_fast(S, r, h, w, stack, 256);
-                const bool vis = (ok ? S.tris[h.leaf].material : -1) == expect;
-                L_dir.x += vis ? c.x : c.x * 0.0;
-                L_dir.y += vis ? c.y : c.y * 0.0;
-                L_dir.z += vis ? c.z : c.z * 0.0;
-            }
-        }
-        int bt = -1;
-        V3 wgt = mk(1, 1, 1);
-        Ray br; br.o = p; br.d = mk(1, 1, 1);
-        if (mode == M_VERTEX && !ended) {
-            bt = bounce_sample(key, depth, nl, m, dir, pn, kd, br.d, wgt);
-            if (bt >= 0) ls.bounce++;
-        } else if (mode == M_ADOPTED) {
-            bt = a.out.btype[j];
-            if (bt >= 0) { br.d = ldc(a.out.bdir, cap, j); if (!folded) wgt = ldc(a.out.w, cap, j); }
-        }
-        if (bt >= 0 && !(bt & MCPT_BT_NO_OFFSET)) br.o = p + br.d * 0.01;
-
-#ifdef MCPT_TRACE_DIAG
-        fin_iters++;
-        const unsigned long long fin_ta = __builtin_amdgcn_s_memtime();
-#endif
-        // ---- closest hits.  One light: a lane with both rays hands its shadow ray to lane ^ 32 when that lane has no path, so
-        // the two walks of a vertex run side by side -- it is the last few long paths, alone in their waves, that decide how long
-        // this kernel runs.  Lanes without a free partner walk the shadow ray first and the bounce ray in a second round.
-        bool b_ok = false;
-        Hit b_hit; b_hit.leaf = -1; b_hit.t = 0; b_hit.p = mk(0, 0, 0);
-        if (nl == 1) {
-            const bool have_s = expect0 != -2, have_b = bt >= 0;
-            const int partner = lane ^ 32;
-            const unsigned long long idle_now = __ballot(mode == M_IDLE);
-            const bool give = have_s && have_b && ((idle_now >> partner) & 1ull);
-            Ray rin;
-            rin.o = mk(__shfl(rs.o.x, partner, 64), __shfl(rs.o.y, partner, 64), __shfl(rs.o.z, partner, 64));
-            rin.d = mk(__shfl(rs.d.x, partner, 64), __shfl(rs.d.y, partner, 64), __shfl(rs.d.z, partner, 64));
-            const int partner_gives = __shfl((int)give, partner, 64);      // every lane takes part: not under a short-circuit
-            const bool helping = mode == M_IDLE && partner_gives != 0;
-            // first round: the helper's ray, or the bounce ray if the shadow ray was handed over, or the own shadow ray
-            const int kind = helping ? 2 : (give ? 1 : (have_s ? 0 : (have_b ? 1 : -1)));
-            Ray r1 = helping ? rin : (kind == 1 ? br : rs);
-            Hit h1; h1.leaf = -1; h1.t = 0; h1.p = mk(0, 0, 0);
-            bool ok1 = false;
-            if (kind >= 0) ok1 = trace_lane_fast(S, r1, h1, w, stack, 256);
-            const int mat1 = (kind == 0 || kind == 2) ? (ok1 ? S.tris[h1.leaf].material : -1) : -1;
-            const int mat_helped = __shfl(mat1, partner, 64);
-            if (have_s) {
-                const bool vis = (give ? mat_helped : mat1) == expect0;
-                L_dir.x += vis ? c0.x : c0.x * 0.0;
-                L_dir.y += vis ? c0.y : c0.y * 0.0;
-                L_dir.z += vis ? c0.z : c0.z * 0.0;
-            }
-            if (kind == 1) { b_ok = ok1; b_hit = h1; }
-            const bool second = have_b && kind == 0;
-            if (__ballot(second)) { if (second) b_ok = trace_lane_fast(S, br, b_hit, w, stack, 256); }
-        } else if (bt >= 0) b_ok = trace_lane_fast(S, br, b_hit, w, stack, 256);
-#ifdef MCPT_TRACE_DIAG
-        fin_t_trace += __builtin_amdgcn_s_memtime() - fin_ta;
-#endif
-        if (mode == M_ADOPTED && folded) L = L + L_dir;                 // its c was stored as T * c
-        else L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
-
-        bool goes_on = false;
-        if (bt >= 0 && b_ok) {
-            // an adopted path with one light already holds the throughput after its bounce
-            if (!(mode == M_ADOPTED && folded)) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
-            leaf = b_hit.leaf; p = b_hit.p; dir = neg(br.d); in_type = bt & 7; depth++;
-            goes_on = true;
-        }
-        if (mode != M_IDLE) {
-            if (goes_on) mode = M_VERTEX;
-            else { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; mode = M_IDLE; }
-        }
-    }
-#ifdef MCPT_TRACE_DIAG
-    if (lane == 0 && a.ctr) {
-        const unsigned long long life = __builtin_amdgcn_s_memtime() - fin_t0;
-        atomicMax(&a.ctr->pad[13], fin_iters);
-        atomicMax(&a.ctr->pad[14], life);
-        atomicMax(&a.ctr->pad[15], fin_t_trace);
-    }
-#endif
-    ls.nodes += w.nodes; ls.tris += w.tris;
-    flush_stats(a.ctr, ls);
-}
-
-// one PrimarySurface per hit pixel of the chunk (same arithmetic as the per-sample code it replaces: vertex_surface)
-__global__ void k_primary_surface(DScene S, WfArgs a, PrimarySurface* __restrict__ surf, unsigned int* __restrict__ alive_count)
-{
-    const unsigned int n = a.counts_in->n_next;
-    const unsigned int n_round = (n + 63u) / 64u * 64u;              // whole waves take part in the ballot below
-    const int lane = threadIdx.x & 63;
-    for (unsigned int h = blockIdx.x * blockDim.x + threadIdx.x; h < n_round; h += gridDim.x * blockDim.x) {
-        bool shaded = false;
-        PrimarySurface r;
-        if (h < n) {
-        const int slot = a.hit_slots[h];
-        const PrimaryHit ph = a.hits[slot];
-        const int pix = a.pixels ? a.pixels[slot] : slot;
-        const V3 p = mk(ph.p[0], ph.p[1], ph.p[2]), dir = neg(ld3(a.dirs + (size_t)pix * 3));
-        r.p[0] = p.x; r.p[1] = p.y; r.p[2] = p.z; r.dir[0] = dir.x; r.dir[1] = dir.y; r.dir[2] = dir.z;
-        r.leaf = ph.leaf; r.material = S.tris[ph.leaf].material; r.pixel = pix; r.slot = slot;
-        V3 pn = mk(0, 0, 0), kd = mk(0, 0, 0);
-        const DMaterial* m = S.materials + r.material;
-        if (m->light < 0) { vertex_surface(S, ph.leaf, p, m, pn, kd); shaded = true; }
-        r.pn[0] = pn.x; r.pn[1] = pn.y; r.pn[2] = pn.z; r.kd[0] = kd.x; r.kd[1] = kd.y; r.kd[2] = kd.z;
-        r.pad[0] = r.pad[1] = r.pad[2] = 0;
-        }
-        // the shaded pixels of the chunk are numbered in slot order (paths in another order trace measurably slower on a rank's
-        // share of a frame): here the rank within the wave and the wave's count, k_alive_scan turns the counts into offsets
-        const unsigned long long bal = __ballot(shaded);
-        if (lane == 0) alive_count[h >> 6] = (unsigned int)__popcll(bal);
-        if (h < n) {
-            r.alive_index = shaded ? (int32_t)__popcll(bal & ((1ull << lane) - 1ull)) : -1;
-            surf[h] = r;
-        }
-    }
-}
-
-// exclusive prefix over the per-wave counts of k_primary_surface (at most a few thousand: one block), total -> *total_out
-__global__ void __launch_bounds__(1024) k_alive_scan(const WfCounts* __restrict__ counts_in, unsigned int* __restrict__ wave_count, unsigned int* __restrict__ total_out)
-{
-    __shared__ unsigned int part[1024];
-    const unsigned int n_waves = (counts_in->n_next + 63u) / 64u;
-    const unsigned int per = (n_waves + 1023u) / 1024u;
-    const unsigned int b = threadIdx.x * per, e = b + per < n_waves ? b + per : n_waves;
-    unsigned int sum = 0;
-    for (unsigned int i = b; i < e; i++) sum += wave_count[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (unsigned int off = 1; off < 1024; off <<= 1) {
-        const unsigned int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned int run = part[threadIdx.x] - sum;              // exclusive prefix of this thread's range
-    for (unsigned int i = b; i < e; i++) { const unsigned int c = wave_count[i]; wave_count[i] = run; run += c; }
-    if (threadIdx.x == 1023) *total_out = part[1023];
-}
-
-
-// slots of this chunk whose primary ray hit something, in slot order within a wave
-__global__ void k_hit_slots(const PrimaryHit* __restrict__ hits, int first_slot, int n_slots, int32_t* __restrict__ hit_slots, unsigned int* count)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool hit = s < n_slots && hits[first_slot + s].leaf >= 0;
-    const unsigned long long bal = __ballot(hit);
-    const int lane = threadIdx.x & 63;
-    unsigned int base = 0;
-    if (lane == 0 && bal) base = atomicAdd(count, (unsigned int)__popcll(bal));
-    base = __shfl(base, 0, 64);
-    if (hit) hit_slots[base + __popcll(bal & ((1ull << lane) - 1ull))] = first_slot + s;
-}
-
-__global__ void k_zero(double* __restrict__ p, long long n)
-{
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.0;
-}
-
 // ---------------------------------------------------------------------------------------------- launchers
 static unsigned grid_for(long long n, int block, unsigned cap_blocks)
 {
     long long b = (n + block - 1) / block;
     if (b < 1) b = 1;
     return (unsigned)(b > cap_blocks ? cap_blocks : b);
-}
-
-void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, unsigned int* alive_count, unsigned int* alive_total, int n_slots_upper,
-                            hipStream_t st)
-{
-    if (n_slots_upper <= 0) return;
-    hipLaunchKernelGGL(k_primary_surface, dim3(grid_for(n_slots_upper, 256, 4096)), dim3(256), 0, st, S, a, surf, alive_count);
-    hipLaunchKernelGGL(k_alive_scan, dim3(1), dim3(1024), 0, st, a.counts_in, alive_count, alive_total);
-}
-
-// A resident-size grid whose blocks stride over the paths: starting a block of this kernel is expensive (large kernarg,
-// 160+ VGPRs, scratch), so 768 long-lived blocks beat 16 k short ones by 15 % of a frame at N=1 and 30 % at one eighth
-// of a frame (measured: MCPT_LOGIC_GRID sweep).
-void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st, const LaunchCfg& cfg)
-{
-    if (n_upper <= 0) return;
-    // small inputs get small grids (>= 1024 paths per block): every wave that starts costs a few atomics on shared counters
-    unsigned g = grid_for(n_upper, 1024, first ? cfg.logic_first : cfg.logic_rest);
-    if (first) hipLaunchKernelGGL(k_wf_logic<true>, dim3(g), dim3(256), 0, st, S, a);
-    else hipLaunchKernelGGL(k_wf_logic<false>, dim3(g), dim3(256), 0, st, S, a);
 }
 
 // Can this device hold a workgroup of the pool engine (1024 threads, 159 KB of LDS)?  Asked once per process; the closest-hit forms of
@@ -730,11 +191,9 @@ void init_launch_cfg(LaunchCfg& cfg)
     if (cfg.cus <= 0) cfg.cus = 256;
     const char* e = std::getenv("MCPT_LOGIC_GRID");
     const unsigned forced = e ? unsigned(std::atoi(e)) : 0u;
-    cfg.logic_first = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<true>), cfg.cus));
-    cfg.logic_rest = forced ? forced : unsigned(persistent_grid(reinterpret_cast<const void*>(k_wf_logic<false>), cfg.cus));
+    init_launch_cfg_logic(cfg, forced);             // wavefront_logic.hip: resident grids of k_wf_logic and k_wf_finish
     cfg.trace_grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace<MCPT_FAST_STACK, 3>), cfg.cus);
     cfg.trace_grid_short = persistent_grid(reinterpret_cast<const void*>(k_wf_trace<kFastShortStack, 4>), cfg.cus);
-    cfg.finish_grid = persistent_grid(reinterpret_cast<const void*>(k_wf_finish), cfg.cus);
     // a wave that starts pays one atomic on the queue head and a few on the counters: give every block >= 2048 rays
     e = std::getenv("MCPT_TRACE_BLOCK_RAYS");
     long long v = e ? std::atoll(e) : 0;
@@ -784,24 +243,6 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
     } else if (shallow) hipLaunchKernelGGL((k_wf_trace<kFastShortStack, 4>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
     else hipLaunchKernelGGL((k_wf_trace<MCPT_FAST_STACK, 3>), dim3(g), dim3(256), 0, st, S, a, queue, slow_list, slow_cap, cfg.min_chunk, cfg.max_chunk);
     hipLaunchKernelGGL(k_wf_trace_slow, dim3(g < 512 ? g : 512), dim3(256), 0, st, S, a, queue, slow_list, slow_cap);   // (blocks without work leave at once)
-}
-
-void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st, const LaunchCfg& cfg)
-{
-    if (n_upper <= 0) return;
-    hipLaunchKernelGGL(k_wf_finish, dim3(grid_for(n_upper, 256, unsigned(cfg.finish_grid))), dim3(256), 0, st, S, a);
-}
-
-void launch_hit_slots(const PrimaryHit* hits, int first_slot, int n_slots, int32_t* hit_slots, unsigned int* count, hipStream_t st)
-{
-    if (n_slots <= 0) return;
-    hipLaunchKernelGGL(k_hit_slots, dim3((n_slots + 255) / 256), dim3(256), 0, st, hits, first_slot, n_slots, hit_slots, count);
-}
-
-void launch_zero_rad(double* rad, long long n, hipStream_t st)
-{
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_zero, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, rad, n);
 }
 
 }  // namespace mcpt

@@ -98,8 +98,13 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& a, WfSta
 void launch_wf_logic(const DScene& S, const WfArgs& a, long long n_upper, bool first, hipStream_t st, const LaunchCfg& cfg);
 void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool fast, TraceQueue* queue, long long* slow_list,
                      unsigned int slow_cap, hipStream_t st, const LaunchCfg& cfg);
-void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st, const LaunchCfg& cfg);
+// path_area: finish_pool_bytes() of device memory for the pool form of the finishing pass (or null: the one-lane-per-path form);
+// slow_list / slow_cap: the frame slot's deferred-ray list, behind which the pool engine's stack spill area lies
+void launch_wf_finish(const DScene& S, const WfArgs& a, long long n_upper, hipStream_t st, const LaunchCfg& cfg, char* path_area, long long* slow_list,
+                      unsigned int slow_cap);
+size_t finish_pool_bytes(int cus, int nl);
 int persistent_grid(const void* kernel, int cus);   // blocks of 256 threads of `kernel` resident on the current device
+void init_launch_cfg_logic(LaunchCfg& cfg, unsigned forced_grid);   // wavefront_logic.hip: logic_first / logic_rest / finish_grid of cfg
 long long persistent_chunk(long long total, int grid_blocks);
 
 void launch_primary_surface(const DScene& S, const WfArgs& a, PrimarySurface* surf, unsigned int* alive_count, unsigned int* alive_total, int n_slots_upper,
