@@ -112,7 +112,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(scene_dir, name, seed, target_seconds=15.0):
+def cpu_baseline(scene_dir, name, seed, target_seconds=15.0, frame_spp=256):
     """The oracle (CPU port of the reference, reference-like cost: primary ray re-traced per sample, light CDF
     rebuilt per shade call) on a bounded sample of the same workload: every 8th row of the frame, all columns,
     at an SPP sized for ~target_seconds, on the physical cores of one socket (OpenMP over row x 64-column blocks;
@@ -138,11 +138,33 @@ def cpu_baseline(scene_dir, name, seed, target_seconds=15.0):
         t0 = time.time()
         osc.render_strided(spp, seed, stride, faithful_cost=True, nthreads=cores, stats=st, img=img)
         dt = time.time() - t0
+        # The reference-style figure SURVEY 8(d) asks for beside it: the reference's own parallel structure -- one pixel at a time, its
+        # samples on min(SPP, 8) OpenMP threads, a team forked and joined per pixel (MTPC/pathTracing.cpp:300-320) -- on a pixel lattice
+        # of the same frame at the frame's SPP, sized for about a third of the time budget.
+        ref_threads = min(frame_spp, 8)
+        rs, cs = 48, 64
+        sr0 = O.Stats()
+        t0 = time.time()
+        osc.render_reference_style(frame_spp, seed, rs * 4, cs * 4, stats=sr0, img=img)
+        dtr0 = max(time.time() - t0, 1e-3)
+        # (the calibration lattice is a sixteenth of the timed one)
+        scale = max(1.0, min(16.0, (target_seconds / 3.0) / (dtr0 * 16.0)))
+        rs2 = max(8, int(rs / scale ** 0.5)); cs2 = max(8, int(cs / scale ** 0.5))
+        sr = O.Stats()
+        t0 = time.time()
+        osc.render_reference_style(frame_spp, seed, rs2, cs2, stats=sr, img=img)
+        dtr = time.time() - t0
     finally:
         os.sched_setaffinity(0, old)
     rays = st.rays
     nrows = (osc.height + stride - 1) // stride
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    reference_style = {
+        "value": sr.rays / dtr / 1e6, "unit": "Mrays/s", "threads": ref_threads,
+        "sample": "%s %dx%d, pixels (%d k, %d m) at SPP %d, seed %d: %d samples, %d rays in %.1f s; the oracle in reference-cost mode with the "
+                  "reference's parallel structure: one pixel at a time, min(SPP, 8) = %d OpenMP threads over its samples, a team forked and "
+                  "joined per pixel (MTPC/pathTracing.cpp:300-320)" % (name, osc.width, osc.height, rs2, cs2, frame_spp, seed, sr.samples, sr.rays, dtr, ref_threads),
+        "samples_per_s": sr.samples / dtr, "seconds": dtr}
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "reference_style": reference_style,
             "sample": "%s %dx%d, rows 0,%d,%d,.. (%d rows, all columns) at SPP %d, seed %d: %d samples, %d rays in %.1f s; oracle in "
                       "reference-cost mode (primary ray re-traced per sample, light CDF rebuilt per shade call); OpenMP over "
                       "row x 64-column blocks on %d threads = physical cores of socket 0 (%s)"
@@ -406,24 +428,29 @@ def main():
     traffic, traffic_src, issue = None, None, None
     # the dominant kernel: one launch per bounce iteration of the closest-hit engine the library picked for this scene
     dom_kernel = "k_wf_trace_pool" if res.get("engine") == "pool" else "k_wf_trace"
-    headline = (args.scene == "cornell-box" and (args.width, args.height, args.spp) == (1280, 720, 256) and world == 1 and args.sim_world <= 1
-                and not args.pipeline)
-    if headline:
-        tf, tj, why = committed_profile("r*_final_hbm_traffic.json", res["build_id"], dom_kernel)
+    # workloads whose command tools/final_profile.sh also runs under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes): tag of the file
+    PROFILED = {("cornell-box", 1280, 720, 256): "final", ("veach-mis", 1280, 720, 100): "veach_mis", ("interior", 1280, 720, 256): "interior",
+                ("synthetic", 1280, 720, 16): "synthetic10m"}
+    tag = PROFILED.get((args.scene, args.width, args.height, args.spp)) if (world == 1 and args.sim_world <= 1 and not args.pipeline and
+                                                                            (args.scene != "synthetic" or args.tris == 10_000_000)) else None
+    headline = tag == "final"
+    if tag is not None:
+        tf, tj, why = committed_profile("r*_%s_hbm_traffic.json" % tag, res["build_id"], dom_kernel)
         if tj is not None:
             traffic = tj["bytes_per_launch"]
             traffic_src = ("from_committed_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per the gfx950 "
                            "note), taken with this build (%s); not measured in this run" % (os.path.relpath(tf, ROOT), res["build_id"]))
         else:
             traffic_src = why
-        uf, uj, why = committed_profile("r*_final_issue_utilisation.json", res["build_id"], dom_kernel)
-        if uj is not None:
-            issue = uj
-            issue["source"] = "from_committed_profile: %s, taken with this build; not measured in this run" % os.path.relpath(uf, ROOT)
-        else:
-            issue = {"source": why}
+        if headline:
+            uf, uj, why = committed_profile("r*_final_issue_utilisation.json", res["build_id"], dom_kernel)
+            if uj is not None:
+                issue = uj
+                issue["source"] = "from_committed_profile: %s, taken with this build; not measured in this run" % os.path.relpath(uf, ROOT)
+            else:
+                issue = {"source": why}
     else:
-        traffic_src = "not the headline workload: no PMC pass of this command is committed"
+        traffic_src = "not a profiled workload: no PMC pass of this command is committed"
     config = {"workload": "%s %dx%d SPP=%d" % (args.scene, args.width, args.height, args.spp), "seed": args.seed,
               "partition": "32x8-pixel tiles dealt along a shifted diagonal over the ranks, compact pixel buffers gathered into rank 0's HBM",
               "primary_rays": "traced once per pixel (identical for every sample: the reference has no jitter)",
@@ -462,7 +489,7 @@ def main():
     if args.save_png and res["frame"] is not None:
         M.write_png(args.save_png, M.imshow_rgb8(res["frame"]))
     if world == 1 and not args.no_cpu_baseline and scene_dir is not None and args.scene != "interior":
-        cb = cpu_baseline(scene_dir, args.scene, args.seed, args.cpu_seconds)
+        cb = cpu_baseline(scene_dir, args.scene, args.seed, args.cpu_seconds, args.spp)
         out["cpu_baseline"] = cb
         out["gpu_over_cpu_mrays"] = value / cb["value"]
         # frame-time ratio: CPU seconds for the full frame extrapolated linearly in samples

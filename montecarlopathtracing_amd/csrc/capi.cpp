@@ -994,6 +994,15 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s)
                      c.trace_rays, per(c.trace_nodes, c.trace_rays), per(c.trace_tris, c.trace_rays), per(c.trace_exact, c.trace_rays), 100.0 * per(c.trace_exact, c.trace_tris));
         std::fprintf(stderr, "rays deferred to the exact walk by k_wf_trace: %llu of %llu\n", c.pad[12], c.trace_rays);
 #ifdef MCPT_POOL_DEBUG
+        if (c.pp[19]) {
+            static const char* nm[5] = {"node", "leaf", "exact", "result", "shade"};
+            const double life = double(c.pp[18]);
+            for (int i = 0; i < 5; i++)
+                std::fprintf(stderr, "path pool %-6s: %10llu steps, %5.1f lanes per step, %7.0f cycles per step, %5.1f %% of wave time\n", nm[i], c.pp[i],
+                             c.pp[i] ? double(c.pp[5 + i]) / c.pp[i] : 0.0, c.pp[i] ? double(c.pp[12 + i]) / c.pp[i] : 0.0, life ? 100.0 * c.pp[12 + i] / life : 0.0);
+            std::fprintf(stderr, "path pool: %llu waves, %.0f cycles per wave, vote + claim + sleep %.1f %% of wave time, %llu sleeps, %llu steps that claimed nothing\n", c.pp[19],
+                         life / c.pp[19], life ? 100.0 * c.pp[17] / life : 0.0, c.pp[10], c.pp[11]);
+        }
         for (int i = 0; i < 4; i++) std::fprintf(stderr, "pool class %d: %llu steps, %.1f lanes per step (%.1f could before the claim)\n", i, c.dbg[8 + i], c.dbg[8 + i] ? double(c.dbg[12 + i]) / c.dbg[8 + i] : 0.0, c.dbg[8 + i] ? double(c.dbg[16 + i]) / c.dbg[8 + i] : 0.0);
         std::fprintf(stderr, "pool: %llu sleeps, %llu steps that claimed nothing\n", c.dbg[20], c.dbg[21]);
         std::fprintf(stderr, "pool debug: %llu launches, %llu slots in all, %llu consumed in %llu refill steps, %llu rays among them, %llu started, %llu slots retired, %llu tickets\n", c.dbg[5], c.dbg[4], c.dbg[0], c.dbg[2], c.dbg[1], c.dbg[7], c.dbg[3], c.dbg[6]);

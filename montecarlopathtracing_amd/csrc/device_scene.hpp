@@ -127,6 +127,9 @@ struct DCounters {
     unsigned long long trace_rays, trace_nodes, trace_tris;   // work done inside the dominant kernel (k_wf_trace) only
     unsigned long long trace_exact;                           // ... triangles of those that survived the pre-test (exact fp64 tests)
     unsigned long long dbg[24];   // MCPT_PRE_CHECK builds: what the pre-test saw of the first triangle it should not have rejected
+    unsigned long long pp[24];    // MCPT_POOL_DEBUG builds, pool form of the finishing pass: [0..4] steps per class (node, leaf, exact, result, shade),
+                                  // [5..9] lanes that claimed, [10] sleeps, [11] steps that claimed nothing, [12..16] wave cycles per class,
+                                  // [17] cycles voting / claiming / sleeping, [18] wave lifetimes, [19] waves
     unsigned long long pad[24];   // diagnostics: [0..11] trace engine (MCPT_TRACE_DIAG builds), [12] rays k_wf_trace handed to the exact walk,
                                   // [13..15] finishing kernel, [16..19] logic kernel
 };

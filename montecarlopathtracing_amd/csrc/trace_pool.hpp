@@ -103,6 +103,20 @@ struct alignas(16) PoolOxy { double ox, oy; };
 struct alignas(16) PoolOzDx { double oz, dx; };
 struct alignas(16) PoolDyz { double dy, dz; };
 struct alignas(16) PoolRcp { float rx, ry, rz, limit; };    // 1/d as floats; the walk's current limit
+// A 16-byte group is read as ONE 16-byte access: left to itself the compiler splits a struct of two doubles into two 8-byte loads and
+// merges them again as ds_read2_b64 offset1:1 -- two 8-byte halves at a 16-byte lane stride, which the LDS serves at a quarter of the rate
+// of ds_read_b128 (8 bank-conflict cycles per instruction: tools/probes/lds_conflict_probe.hip; that was most of the 22 % of
+// SQ_LDS_BANK_CONFLICT in SQ_LDS_IDX_ACTIVE the round-3 profile of this kernel shows).
+typedef double pool_d2 __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ T pool_ld16(const T* p)
+{
+    static_assert(sizeof(T) == 16, "16-byte group");
+    const pool_d2 v = *reinterpret_cast<const pool_d2*>(p);
+    T r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
 
 // Every array is [k][lane] (a 16-byte group per lane where a step wants the words together, else one word per lane): consecutive lanes
 // touch consecutive banks whatever their k, so a 4-byte access of a step has no bank conflict.  (Single words inside 16-byte groups
@@ -190,6 +204,9 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 #ifdef MCPT_POOL_DEBUG
     unsigned long long d_used = 0, d_okc = 0, d_steps = 0, d_kill = 0, d_tickets = 0;
     unsigned long long d_cs[5] = {0, 0, 0, 0, 0}, d_cl[5] = {0, 0, 0, 0, 0}, d_sleep = 0, d_miss = 0, d_want[5] = {0, 0, 0, 0, 0};
+    unsigned long long d_cyc[6] = {0, 0, 0, 0, 0, 0};      // wave cycles per class, [5]: voting, claiming, sleeping
+    unsigned long long d_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long d_t0 = d_t;
 #endif
     long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk of source slots
     bool queue_empty = false;
@@ -345,6 +362,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         if (!hv) continue;
         const int n_have = __popcll(hv);
 #ifdef MCPT_POOL_DEBUG
+        { const unsigned long long tn = __builtin_amdgcn_s_memtime(); d_cyc[5] += tn - d_t; d_t = tn; }
         d_cs[c]++; d_cl[c] += n_have; d_want[c] += c == C_INNER ? n_inner : (c == C_LEAF ? n_leaf : (c == C_EXACT ? n_exact : (c == C_FIN ? n_fin : n_shade)));
 #endif
         const int idx = k * 64 + lane;
@@ -357,7 +375,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
             if (have) {
                 const int cur = L.cur[idx];
                 const int spf = L.spf[idx];
-                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolRcp a4 = L.rcp[idx];
+                const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolRcp a4 = L.rcp[idx];
                 const float limit = a4.limit;
                 int sp = spf & 255;
                 if (sp > stack_cap - 3) {        // three pushes must fit: the ray goes to the one-lane walk
@@ -389,7 +407,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 const int cur = L.cur[idx];
                 const int spf0 = L.spf[idx];
                 const int cnt = (spf0 >> 16) & 255;
-                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx]; const PoolRcp a4 = L.rcp[idx];
+                const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolDyz a2 = pool_ld16(&L.dyz[idx]); const PoolRcp a4 = L.rcp[idx];
                 const float of[3] = {(float)a0.ox, (float)a0.oy, (float)a1.oz};
                 const float limit = a4.limit, margin = margin_of(of, a4);
                 unsigned int surv = 0;
@@ -440,7 +458,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 const int cur = L.cur[idx];
                 int spf = L.spf[idx];
                 int surv = (spf >> 16) & 255;
-                const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
+                const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolDyz a2 = pool_ld16(&L.dyz[idx]);
                 const double best_t = L.best_t[idx];
                 Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
                 const int kk = __ffs(surv) - 1;
@@ -488,7 +506,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 // (reference leaf in best_leaf, its material in cur; the ray itself stays where it is: the SHADE step forms the hit point from it)
                 if (have) {
                     const int spf = L.spf[idx];
-                    const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
+                    const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolDyz a2 = pool_ld16(&L.dyz[idx]);
                     Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
                     bool found = (spf & F_FOUND) != 0;
                     bool ambiguous = (spf & F_AMBIG) != 0;
@@ -567,7 +585,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                         // an adopted path with one light already holds the throughput after its bounce
                         if (!(mode == P_ADOPTED && folded)) { const V3 wgt = ldp(RD_W); T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR); }
                         // the hit point: the first two lines of the reference's triangle test on the ray that is still in its slot
-                        const PoolOxy b0 = L.oxy[bidx]; const PoolOzDx b1 = L.ozdx[bidx]; const PoolDyz b2 = L.dyz[bidx];
+                        const PoolOxy b0 = pool_ld16(&L.oxy[bidx]); const PoolOzDx b1 = pool_ld16(&L.ozdx[bidx]); const PoolDyz b2 = pool_ld16(&L.dyz[bidx]);
                         const V3 ro = mk(b0.ox, b0.oy, b1.oz), bd = mk(b1.dx, b2.dy, b2.dz);
                         const DTri* tr = S.tris + hl;
                         const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
@@ -705,7 +723,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
             if (have) {
                 const int spf = L.spf[idx];
                 if (spf & F_RAY) {
-                    const PoolOxy a0 = L.oxy[idx]; const PoolOzDx a1 = L.ozdx[idx]; const PoolDyz a2 = L.dyz[idx];
+                    const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolDyz a2 = pool_ld16(&L.dyz[idx]);
                     const long long slot = (long long)L.q[idx];
                     Ray r; r.o = mk(a0.ox, a0.oy, a1.oz); r.d = mk(a1.dx, a2.dy, a2.dz);
                     const bool found = (spf & F_FOUND) != 0;
@@ -806,6 +824,9 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
             if (n_dead && lane == 0) __hip_atomic_fetch_sub(&L.live, (unsigned int)n_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __asm__ volatile("" ::: "memory");
+#ifdef MCPT_POOL_DEBUG
+        { const unsigned long long tn = __builtin_amdgcn_s_memtime(); d_cyc[c] += tn - d_t; d_t = tn; }
+#endif
 #if MCPT_POOL_STICKY
         if (have && c == C_INNER && nc == C_INNER) { keep = true; keep_k = k; nc = C_DEAD; }      // (not filed: it stays with this lane)
 #endif
@@ -816,6 +837,14 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     junk += pf;
     if (lane == 0) { w.nodes += c_nodes + (junk == 0x9e3779b9u ? 1u : 0u); w.rays += c_rays; w.exact += c_exact; }
 #ifdef MCPT_POOL_DEBUG
+    if constexpr (PP::kPaths) {
+        if (lane == 0 && pp.a.ctr) {
+            unsigned long long* o = pp.a.ctr->pp;
+            for (int i = 0; i < 5; i++) { atomicAdd(&o[i], d_cs[i]); atomicAdd(&o[5 + i], d_cl[i]); atomicAdd(&o[12 + i], d_cyc[i]); }
+            atomicAdd(&o[10], d_sleep); atomicAdd(&o[11], d_miss); atomicAdd(&o[17], d_cyc[5]);
+            atomicAdd(&o[18], __builtin_amdgcn_s_memtime() - d_t0); atomicAdd(&o[19], 1ull);
+        }
+    } else
     if (lane == 0 && w.dbg) {
         atomicAdd(&w.dbg[0], d_used); atomicAdd(&w.dbg[1], d_okc); atomicAdd(&w.dbg[2], d_steps); atomicAdd(&w.dbg[3], d_kill); atomicAdd(&w.dbg[6], d_tickets);
         atomicAdd(&w.dbg[7], (unsigned long long)c_rays);

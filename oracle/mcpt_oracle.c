@@ -1097,6 +1097,53 @@ void orc_render(const orc_scene* s, int spp, uint64_t seed, int row0, int row1, 
     if (st) stats_add(st, &total);
 }
 
+/* The reference's own parallel structure, for timing (MTPC/pathTracing.cpp:300-320): the samples of ONE pixel at a time on
+ * min(spp, 8) OpenMP threads -- a team forked and joined per pixel, as `omp_set_num_threads(min(N, 8)); #pragma omp parallel for`
+ * over k does there -- every sample re-tracing the primary ray and rebuilding the light CDF per shade call (faithful cost).  The
+ * reference adds the samples under a mutex in whatever order the threads arrive; here they are summed in sample order after the join
+ * (D3), so the picture equals orc_render's.  Pixels: rows 0, row_stride, ... x columns 0, col_stride, ... */
+void orc_render_reference_style(const orc_scene* s, int spp, uint64_t seed, int row_stride, int col_stride, double* img, orc_stats* st)
+{
+    CamFrame cf = cam_frame(s);
+    const int W = s->width, H = s->height;
+    const int team = spp < 8 ? spp : 8;
+    vec3* rad = (vec3*)malloc(sizeof(vec3) * (size_t)spp);
+    orc_stats total; memset(&total, 0, sizeof total);
+    for (int i = 0; i < H; i++) {
+        vec3 pos = vsub(cf.start_point, vmul(cf.screen_pdy, i));
+        for (int j = 0; j < W; j++) {
+            if (i % row_stride == 0 && j % col_stride == 0) {
+                const RayT ray = { cf.eye, vnormalize(vsub(pos, cf.eye)) };
+#ifdef _OPENMP
+                omp_set_num_threads(team);
+#endif
+#pragma omp parallel
+                {
+                    orc_stats local; memset(&local, 0, sizeof local);
+                    uint64_t box = 0, tri = 0;
+#pragma omp for schedule(static)
+                    for (int k = 0; k < spp; k++) {
+                        Ctx c = { s, seed, (uint32_t)(i * W + j), (uint32_t)k, 1, &local, { 0, 0 } };
+                        RayT r = ray;
+                        Hit primary;
+                        rad[k] = sample_radiance(&c, &r, &primary, 0);
+                        box += c.c.box; tri += c.c.tri;
+                    }
+                    local.box_tests += box; local.tri_tests += tri;
+#pragma omp critical
+                    stats_add(&total, &local);
+                }
+                float cr = 0, cg = 0, cb = 0;
+                for (int k = 0; k < spp; k++) { cr += rad[k].x / spp; cg += rad[k].y / spp; cb += rad[k].z / spp; }
+                img[((size_t)i * W + j) * 3 + 0] = cr; img[((size_t)i * W + j) * 3 + 1] = cg; img[((size_t)i * W + j) * 3 + 2] = cb;
+            }
+            pos = vadd(pos, cf.screen_pdx);
+        }
+    }
+    free(rad);
+    if (st) stats_add(st, &total);
+}
+
 /* imshow, MTPC/MTPC.cpp:22-30: (unsigned char)clamp(v*255, 0, 255) */
 void orc_quantize(const double* img, int64_t n, uint8_t* rgb8)
 {

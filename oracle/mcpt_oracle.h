@@ -129,6 +129,9 @@ void orc_render(const orc_scene*, int spp, uint64_t seed, int row0, int row1, in
 /* rows 0, stride, 2*stride, ... only (bounded CPU-baseline sample); OpenMP over the sampled rows */
 void orc_render_strided(const orc_scene*, int spp, uint64_t seed, int row_stride, int faithful_cost, int nthreads,
                         int unused, double* img, orc_stats* st);
+/* the reference's own parallel structure (one pixel at a time, min(spp, 8) threads over its samples, fork/join per pixel:
+ * MTPC/pathTracing.cpp:300-320), faithful cost, on the pixels (k * row_stride, m * col_stride): the reference-style timing */
+void orc_render_reference_style(const orc_scene*, int spp, uint64_t seed, int row_stride, int col_stride, double* img, orc_stats* st);
 
 /* ---- output: MTPC/MTPC.cpp:10-33, MTPC/svpng.inc:77-107 ---- */
 void orc_quantize(const double* img, int64_t n, uint8_t* rgb8);

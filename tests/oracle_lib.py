@@ -75,6 +75,7 @@ def lib():
         L.orc_primary_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_double), C.POINTER(Stats)]
+        L.orc_render_reference_style.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(Stats)]
         L.orc_render_strided.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_double), C.POINTER(Stats)]
         L.orc_quantize.argtypes = [C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_uint8)]
@@ -217,6 +218,18 @@ def _render_strided(self, spp, seed, row_stride, faithful_cost=True, nthreads=0,
 
 
 OracleScene.render_strided = _render_strided
+
+
+def _render_reference_style(self, spp, seed, row_stride, col_stride, stats=None, img=None):
+    """the reference's own parallel structure (fork/join of min(spp, 8) threads per pixel), faithful cost, on a pixel lattice"""
+    if img is None:
+        img = np.zeros((self.height, self.width, 3))
+    lib().orc_render_reference_style(self.h, spp, seed, row_stride, col_stride, _ptr(img, C.c_double),
+                                     C.byref(stats) if stats is not None else None)
+    return img
+
+
+OracleScene.render_reference_style = _render_reference_style
 
 
 def quantize(img):

@@ -818,12 +818,16 @@ def test_bench_line_keeps_its_contract(tmp_path):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert (r["bytes_per_unit"]["node_visit"], r["bytes_per_unit"]["triangle_test"], r["bytes_per_unit"]["ray"]) == (32, 48, 64)
-    assert r["record_bytes_rate_GBs"] > r["achieved"] and r["traffic"] is None and "not the headline workload" in r["traffic_source"]
+    assert r["record_bytes_rate_GBs"] > r["achieved"] and r["traffic"] is None and "not a profiled workload" in r["traffic_source"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and "traffic" in r
     # the dominant kernel is named after the engine the library picked for the scene (cornell-box: small, hence the pool engine)
     assert (r["engine"], r["kernel"]) in (("pool", "k_wf_trace_pool"), ("vote", "k_wf_trace"))
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
+    # ... and the reference-style figure beside it: the reference's own parallel structure, min(SPP, 8) threads per pixel
+    rs = c["reference_style"]
+    assert rs["threads"] == 8 and rs["value"] > 0 and rs["unit"] == "Mrays/s" and "pathTracing.cpp:300-320" in rs["sample"]
+    assert rs["value"] < c["value"]             # <= 8 threads and a fork/join per pixel against every core of the socket
 
 
 def test_bench_refuses_more_gpus_than_visible_and_quotes_only_profiles_of_the_loaded_build(mcpt, tmp_path):

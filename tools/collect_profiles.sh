@@ -10,6 +10,11 @@ cp $t/pmc_hbm_traffic.txt ${p}_pmc_hbm_traffic.txt
 cp $t/pmc_sq/summary.txt ${p}_pmc_sq_tcp.txt
 cp $t/timeline_one_eighth.txt ${p}_timeline_one_eighth_frame.txt
 [ -f $t/trace_phases.txt ] && cp $t/trace_phases.txt ${p}_trace_phases.txt
+# the other profiled workloads' traffic (bench.py quotes profiles/rNN_<tag>_hbm_traffic.json for their commands)
+rr=${p%_final}
+for w in veach_mis interior synthetic10m; do
+  [ -f $t/${w}_hbm_traffic.json ] && cp $t/${w}_hbm_traffic.json ${rr}_${w}_hbm_traffic.json && cp $t/${w}_pmc_hbm_traffic.txt ${rr}_${w}_pmc_hbm_traffic.txt
+done
 python3 - $t ${p}_other_configs.json <<'PY'
 import json, sys
 t, out = sys.argv[1:3]

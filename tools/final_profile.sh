@@ -39,6 +39,24 @@ timeout -k 10 200 python3 bench.py --scene veach-mis --spp 100 --steps 5 --no-cp
 timeout -k 10 300 python3 bench.py --scene interior --steps 3 --no-cpu-baseline > $out/interior_spp256.json 2>> $out/bench.err
 timeout -k 10 400 python3 bench.py --scene synthetic --spp 16 --steps 3 --no-cpu-baseline > $out/synthetic10m_spp16.json 2>> $out/bench.err
 timeout -k 10 600 python3 bench.py --scene synthetic --width 3840 --height 2160 --spp 1024 --steps 1 --warmup 0 --no-cpu-baseline > $out/synthetic10m_3840x2160_spp1024.json 2>> $out/bench.err
+# FETCH_SIZE / WRITE_SIZE (and the L2 hit / miss counts) of the other profiled workloads, one frame each, program directly after "--":
+# bench.py quotes them as roofline.traffic for those commands (same build-id rule as the headline's)
+other_pmc() { # tag, kernel, bench arguments, command text
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+    n=$(echo $c | cut -d' ' -f1)
+    timeout -k 10 400 rocprofv3 --pmc $c -d $out/pmc_$1/$n -o pmc --output-format csv -- python3 $root/bench.py $3 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$1_$n.log 2>&1
+  done
+  cd $root
+  python3 tools/pmc_to_traffic.py $out/pmc_$1 $2 "python3 bench.py $3 --steps 1 --warmup 0 --no-cpu-baseline" $out/$1_hbm_traffic.json > /dev/null
+  python3 tools/pmc_summary.py $out/pmc_$1 k_wf > $out/$1_pmc_hbm_traffic.txt
+}
+KV=$(python3 -c "import json; print(json.load(open('$out/veach_mis_spp100.json'))['roofline']['kernel'])")
+KI=$(python3 -c "import json; print(json.load(open('$out/interior_spp256.json'))['roofline']['kernel'])")
+KS=$(python3 -c "import json; print(json.load(open('$out/synthetic10m_spp16.json'))['roofline']['kernel'])")
+other_pmc veach_mis $KV "--scene veach-mis --spp 100"
+other_pmc interior $KI "--scene interior"
+other_pmc synthetic10m $KS "--scene synthetic --spp 16"
 # lanes per phase, iterations and the pre-test's share from the in-kernel counters (diagnostic build: variants/libmcpt_diag.so, tools/build_variant.sh diag "-DMCPT_TRACE_DIAG -DMCPT_POOL_DEBUG")
 if [ -f montecarlopathtracing_amd/csrc/variants/libmcpt_diag.so ]; then
   MCPT_LIB=montecarlopathtracing_amd/csrc/variants/libmcpt_diag.so MCPT_PRINT_DIAG=1 timeout -k 10 200 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/diag.json 2> $out/diag.err
