@@ -102,6 +102,10 @@ const char* mcpt_build_id(void);                            /* 16 hex digits: ha
  * (or MCPT_ALLOW_RUNTIME_MISMATCH=1 is set), which turns the refusal into one line on stderr.
  *   mcpt_hip_runtime_info : versions encoded as HIP_VERSION (major * 10^7 + minor * 10^5 + patch); path = the file the runtime was loaded from
  *   mcpt_hip_runtime_check: the comparison itself, a pure function (0 = compatible; msg receives the refusal's text) */
+/* Every environment variable the library reads (since 105), one per line: "NAME | default | meaning".  The environment is parsed when a
+ * device (or multi-device) handle is created and kept in the handle -- never inside a launch -- so two handles created under different
+ * settings keep them; INTEGRATION.md section 7 is this table. */
+const char* mcpt_knobs_describe(void);
 int         mcpt_hip_runtime_info(int32_t* compiled, int32_t* runtime, char* path, int64_t cap);
 int         mcpt_hip_runtime_check(int32_t compiled, int32_t runtime, const char* runtime_path, char* msg, int64_t cap);
 void        mcpt_allow_runtime_mismatch(int32_t allow);

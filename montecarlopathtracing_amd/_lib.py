@@ -67,7 +67,7 @@ class RenderSceneOptions(C.Structure):
 # every symbol include/mcpt.h declares
 EXPORTS = [
     "mcpt_version", "mcpt_last_error", "mcpt_device_count", "mcpt_build_id",
-    "mcpt_hip_runtime_info", "mcpt_hip_runtime_check", "mcpt_allow_runtime_mismatch",
+    "mcpt_knobs_describe", "mcpt_hip_runtime_info", "mcpt_hip_runtime_check", "mcpt_allow_runtime_mismatch",
     "mcpt_scene_load", "mcpt_scene_load_ex", "mcpt_scene_create", "mcpt_scene_free", "mcpt_scene_set_resolution", "mcpt_scene_get_info", "mcpt_scene_get_faces",
     "mcpt_scene_get_leaf_order", "mcpt_scene_get_bvh_nodes", "mcpt_scene_find_index", "mcpt_scene_get_material",
     "mcpt_scene_get_light", "mcpt_morton_code", "mcpt_scene_fast_bvh_stats",
@@ -104,6 +104,7 @@ def lib():
     L.mcpt_last_error.restype = C.c_char_p
     L.mcpt_device_count.restype = C.c_int
     L.mcpt_build_id.restype = C.c_char_p
+    L.mcpt_knobs_describe.restype = C.c_char_p
     L.mcpt_hip_runtime_info.argtypes = [I32, I32, C.c_char_p, C.c_int64]
     L.mcpt_hip_runtime_check.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_int64]
     L.mcpt_allow_runtime_mismatch.argtypes = [C.c_int32]

@@ -32,8 +32,6 @@ namespace {
 
 constexpr int kBins = 16;
 double kCostNode = 1.0;   // relative cost of one inner step (two conservative box tests)
-double kCostTri = 1.6;    // relative cost of one leaf triangle (cheap box reject + some exact tests)
-int kMaxLeafRt = kFastDefaultLeaf;
 
 struct Box {
     double lo[3], hi[3];
@@ -68,6 +66,7 @@ struct Builder {
     std::vector<Subtree>* defer = nullptr;   // top-level pass only: subtrees of at most `cut` primitives are recorded, not built
     int cut = 0;
     int max_leaf = kFastDefaultLeaf;         // most primitives a leaf may hold
+    double cost_tri = 1.6;                   // relative cost of one leaf triangle (FastBuildOpts)
     int depth_limit = kFastMaxDepth;         // binary depth the tree must stay below (the walk's stack)
     // Top-level pass of a large scene: the loops over a node's primitives (bounds, bins, partition) run on `threads` threads while the
     // node has at least kParallelMin of them -- minima, maxima and counts are merged exactly, so the splits are those of the serial
@@ -196,8 +195,8 @@ struct Builder {
                 }
             }
             if (best_axis >= 0) {
-                const double split_cost = kCostNode + kCostTri * best / std::max(parent_area, 1e-300);
-                if (n <= max_leaf && kCostTri * n <= split_cost) return make_leaf(b, e);
+                const double split_cost = kCostNode + cost_tri * best / std::max(parent_area, 1e-300);
+                if (n <= max_leaf && cost_tri * n <= split_cost) return make_leaf(b, e);
                 const int a = best_axis;
                 auto goes_left = [&](int32_t p) {
                     const Vec3& c = cen[p];
@@ -381,13 +380,11 @@ struct Collapser {
 
 }  // namespace
 
-static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int budget0, FastBvh& out);
+static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int budget0, FastBvh& out, const FastBuildOpts& opts);
 
-void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out, int stack_limit)
+void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out, int stack_limit, const FastBuildOpts& opts)
 {
     out = FastBvh();
-    if (const char* e = std::getenv("MCPT_FAST_LEAF")) kMaxLeafRt = std::max(1, std::min(kFastMaxLeaf, std::atoi(e)));
-    if (const char* e = std::getenv("MCPT_FAST_CT")) kCostTri = std::atof(e);
     std::vector<Box> prim(t);
     double amax = 0;
     auto mx3 = [](double a, double b, double c) { if (a >= b && a >= c) return a; if (b >= a && b >= c) return b; return c; };   // dmax
@@ -410,22 +407,22 @@ void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int
         std::lock_guard<std::mutex> lock(amax_mu);
         amax = std::max(amax, am);
     });
-    if (std::getenv("MCPT_PRINT_DIAG")) std::fprintf(stderr, "fast hierarchy (host): leaf boxes %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+    if (opts.talk) std::fprintf(stderr, "fast hierarchy (host): leaf boxes %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     out.scene_absmax = amax;
-    build_from_boxes(prim, kMaxLeafRt, stack_limit - 1, out);
+    build_from_boxes(prim, std::max(1, std::min(kFastMaxLeaf, opts.max_leaf)), stack_limit - 1, out, opts);
     out.stack_limit = stack_limit;
 }
 
 // Upper part of a two-part hierarchy (MCPT_BUILD_DEVICE_FAST): the SAH tree over the boxes of clusters the GPU has built, one
 // cluster per leaf.  lower_need = traversal stack entries a cluster's own subtree needs.  A leaf child of out.cw comes back as
 // -1 - cluster; the caller turns it into the index of that cluster's root node.
-void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out, int stack_limit)
+void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out, int stack_limit, const FastBuildOpts& opts)
 {
     out = FastBvh();
     std::vector<Box> prim(static_cast<size_t>(n), Box{});
     for (int i = 0; i < n; i++)
         for (int a = 0; a < 3; a++) { prim[size_t(i)].lo[a] = boxes6[size_t(i) * 6 + a]; prim[size_t(i)].hi[a] = boxes6[size_t(i) * 6 + 3 + a]; }
-    build_from_boxes(prim, 1, stack_limit - 1 - lower_need, out);
+    build_from_boxes(prim, 1, stack_limit - 1 - lower_need, out, opts);
     out.stack_limit = stack_limit;
     for (CwNode& nd : out.cw)
         for (int c = 0; c < 4; c++)
@@ -464,10 +461,10 @@ static void cw_top_first(std::vector<CwNode>& cw, int n_top)
 }
 
 // binned-SAH binary tree over the boxes, collapsed to compressed 4-wide nodes whose walk needs at most budget0 stack entries
-static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int budget0, FastBvh& out)
+static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int budget0, FastBvh& out, const FastBuildOpts& opts)
 {
     const int t = int(prim.size());
-    const bool talk = std::getenv("MCPT_PRINT_DIAG") != nullptr;
+    const bool talk = opts.talk;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<Vec3> cen(static_cast<size_t>(t), Vec3{});
     std::vector<int32_t> idx(static_cast<size_t>(t), 0);
@@ -479,7 +476,7 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
         }
     });
     Builder bld(prim, cen, idx, out);
-    bld.max_leaf = max_leaf; bld.depth_limit = budget0 + 1;
+    bld.max_leaf = max_leaf; bld.depth_limit = budget0 + 1; bld.cost_tri = opts.cost_tri;
     out.nodes.reserve(size_t(t));
     out.leaf_tris.reserve(size_t(t));
     // Large scenes: the top of the tree is split here, subtrees of <= t/64 primitives are built by worker threads (each into
@@ -488,7 +485,7 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int workers = int(std::min(16u, hw));
     std::vector<int32_t> scratch;
-    if (t >= (1 << 17) && workers > 1 && !std::getenv("MCPT_BUILD_SERIAL")) {
+    if (t >= (1 << 17) && workers > 1 && !opts.serial) {
         bld.defer = &subtrees; bld.cut = std::max(4096, t / 64);
         if (t >= Builder::kParallelMin) { scratch.resize(size_t(t)); bld.scratch = &scratch; bld.threads = workers; }
     }
@@ -509,7 +506,7 @@ static void build_from_boxes(const std::vector<Box>& prim, int max_leaf, int bud
                 Builder wb(prim, cen, idx, part[i]);
                 part[i].nodes.reserve(size_t(subtrees[i].e - subtrees[i].b));
                 part[i].leaf_tris.reserve(size_t(subtrees[i].e - subtrees[i].b));
-                wb.max_leaf = max_leaf; wb.depth_limit = budget0 + 1;
+                wb.max_leaf = max_leaf; wb.depth_limit = budget0 + 1; wb.cost_tri = opts.cost_tri;
                 part_root[i] = wb.build(subtrees[i].b, subtrees[i].e, subtrees[i].depth);
             }
         };

@@ -56,9 +56,17 @@ struct FastBvh {
     int max_depth = 0;
 };
 
+// what the host builder takes from the handle's knobs (knobs.hpp)
+struct FastBuildOpts {
+    int max_leaf = kFastDefaultLeaf;       // MCPT_FAST_LEAF
+    double cost_tri = 1.6;                 // MCPT_FAST_CT: relative cost of one leaf triangle (cheap box reject + some exact tests)
+    bool serial = false;                   // MCPT_BUILD_SERIAL
+    bool talk = false;                     // MCPT_PRINT_DIAG
+};
 // order[k] = .obj face held by reference leaf k
-void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out, int stack_limit = kFastMaxDepth);
+void build_fast_bvh(const std::vector<FaceRec>& faces, const int32_t* order, int t, FastBvh& out, int stack_limit = kFastMaxDepth,
+                    const FastBuildOpts& opts = FastBuildOpts());
 // upper part over n GPU-built clusters given by their boxes (lo[3], hi[3]); see accel_build.cpp
-void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out, int stack_limit = kFastMaxDepth);
+void build_fast_upper(const double* boxes6, int n, int lower_need, FastBvh& out, int stack_limit = kFastMaxDepth, const FastBuildOpts& opts = FastBuildOpts());
 
 }  // namespace mcpt

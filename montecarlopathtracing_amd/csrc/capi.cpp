@@ -23,6 +23,7 @@
 #include "build_kernels.hpp"
 #include "jpeg_decoder.hpp"
 #include "kernels.hpp"
+#include "knobs.hpp"
 #include "scene.hpp"
 #include "wavefront.hpp"
 
@@ -76,30 +77,40 @@ struct mcpt_scene {
     mutable std::mutex fast_mu;
     mutable std::shared_ptr<const FastBvh> fast_cached;
     mutable std::vector<int32_t> fast_order;
+    mutable int fast_leaf = 0;
+    mutable double fast_ct = 0;
 };
 
 // The hierarchy is always built for the deep stack (the better tree); MCPT_FAST_STACK_LIMIT builds it for a shallower one (A/B runs).
-static int stack_limit_for(size_t)
+static int stack_limit_for(const Knobs& k) { return k.fast_stack_limit ? k.fast_stack_limit : kFastMaxDepth; }
+static FastBuildOpts build_opts_for(const Knobs& k)
 {
-    if (const char* e = std::getenv("MCPT_FAST_STACK_LIMIT")) { const int v = std::atoi(e); if (v >= 8 && v <= kFastMaxDepth) return v; }
-    return kFastMaxDepth;
+    FastBuildOpts o;
+    if (k.fast_leaf) o.max_leaf = std::max(1, std::min(kFastMaxLeaf, k.fast_leaf));
+    if (k.fast_ct > 0) o.cost_tri = k.fast_ct;
+    o.serial = k.build_serial != 0; o.talk = k.print_diag != 0;
+    return o;
 }
 
-static std::shared_ptr<const FastBvh> shared_fast_bvh(const mcpt_scene* h, const std::vector<int32_t>& order)
+// (built with the knobs of the device creation that asks first; a later one with other builder knobs rebuilds)
+static std::shared_ptr<const FastBvh> shared_fast_bvh(const mcpt_scene* h, const std::vector<int32_t>& order, const Knobs& k)
 {
     std::lock_guard<std::mutex> lock(h->fast_mu);
-    const int limit = stack_limit_for(h->s.faces.size());
-    if (!h->fast_cached || h->fast_order != order || h->fast_cached->stack_limit != limit) {
+    const int limit = stack_limit_for(k);
+    const FastBuildOpts o = build_opts_for(k);
+    if (!h->fast_cached || h->fast_order != order || h->fast_cached->stack_limit != limit || h->fast_leaf != o.max_leaf || h->fast_ct != o.cost_tri) {
         auto fb = std::make_shared<FastBvh>();
-        build_fast_bvh(h->s.faces, order.data(), int(h->s.faces.size()), *fb, limit);
+        build_fast_bvh(h->s.faces, order.data(), int(h->s.faces.size()), *fb, limit, o);
         h->fast_cached = fb;
         h->fast_order = order;
+        h->fast_leaf = o.max_leaf; h->fast_ct = o.cost_tri;
     }
     return h->fast_cached;
 }
 
 struct mcpt_device {
     int ordinal = 0;
+    Knobs knobs;                           // the environment as it was when this device was created (knobs.hpp)
     DScene ds{};
     hipStream_t stream = nullptr;          // library stream for the host-pointer entry points
     // scene arrays
@@ -164,6 +175,8 @@ extern "C" {
 int mcpt_version(void) { return MCPT_VERSION; }
 const char* mcpt_last_error(void) { return g_error.c_str(); }
 
+const char* mcpt_knobs_describe(void) { return knobs_table(); }
+
 int mcpt_device_count(void)
 {
     int n = 0;
@@ -219,8 +232,7 @@ static int runtime_gate()
     char path[512], msg[1024];
     mcpt_hip_runtime_info(&compiled, &runtime, path, sizeof path);
     if (mcpt_hip_runtime_check(compiled, runtime, path, msg, sizeof msg) == MCPT_OK) return MCPT_OK;
-    const char* e = std::getenv("MCPT_ALLOW_RUNTIME_MISMATCH");
-    if (g_allow_runtime_mismatch.load() || (e && std::atoi(e) != 0)) {
+    if (g_allow_runtime_mismatch.load() || read_knobs().allow_runtime_mismatch) {
         static std::atomic<int> told{0};
         if (!told.exchange(1)) std::fprintf(stderr, "libmcpt: %s -- running anyway, as asked\n", msg);
         return MCPT_OK;
@@ -397,20 +409,16 @@ uint32_t mcpt_morton_code(float x, float y, float z) { return morton_code(x, y, 
 // vote: cornell-box (15 k triangles) 82.0 / 92.3 ms, veach-mis 147.5 / 160.7, one eighth of a cornell-box frame 13.9 / 15.3; the 204 k
 // triangle interior 253 / 250, 10 M triangles 56.3 / 52.8: where the walk waits for memory, the pool engine's longer chain of dependent
 // LDS and memory round trips per step costs what its fuller lanes save, or more.
-static int trace_engine_for(long long t)
+static int trace_engine_for(long long t, const Knobs& k)
 {
-    if (const char* e = std::getenv("MCPT_TRACE_ENGINE")) {
-        if (std::strcmp(e, "pool") == 0) return (mcpt_device_count() > 0 && !pool_engine_available()) ? MCPT_ENGINE_VOTE : MCPT_ENGINE_POOL;
-        if (std::strcmp(e, "vote") == 0) return MCPT_ENGINE_VOTE;
-    }
-    long long max_tris = 1ll << 17;
-    if (const char* e = std::getenv("MCPT_POOL_MAX_TRIS")) max_tris = std::atoll(e);
-    if (t > max_tris) return MCPT_ENGINE_VOTE;
+    if (k.trace_engine == 1) return (mcpt_device_count() > 0 && !pool_engine_available()) ? MCPT_ENGINE_VOTE : MCPT_ENGINE_POOL;
+    if (k.trace_engine == 0) return MCPT_ENGINE_VOTE;
+    if (t > k.pool_max_tris) return MCPT_ENGINE_VOTE;
     // (a device that cannot hold the pool engine's workgroup -- 1024 threads, 159 KB of LDS -- runs the voting engine; without a device
     // the answer is the policy's)
     if (mcpt_device_count() > 0 && !pool_engine_available()) {
-        static bool told = false;
-        if (!told) { told = true; std::fprintf(stderr, "libmcpt: this device cannot hold the pool engine's workgroup; the voting engine runs instead\n"); }
+        static std::atomic<int> told{0};
+        if (!told.exchange(1)) std::fprintf(stderr, "libmcpt: this device cannot hold the pool engine's workgroup; the voting engine runs instead\n");
         return MCPT_ENGINE_VOTE;
     }
     return MCPT_ENGINE_POOL;
@@ -419,7 +427,7 @@ static int trace_engine_for(long long t)
 int mcpt_scene_trace_engine(const mcpt_scene* h)
 {
     if (!h) return fail(MCPT_ERR_ARG, "null argument");
-    return trace_engine_for((long long)h->s.faces.size());
+    return trace_engine_for((long long)h->s.faces.size(), read_knobs());      // (what a device created now would use)
 }
 
 int mcpt_scene_fast_bvh_stats(const mcpt_scene* h, int32_t* n_nodes, int32_t* max_depth, int32_t* leaf_order, int32_t* nesting_ok)
@@ -427,7 +435,7 @@ int mcpt_scene_fast_bvh_stats(const mcpt_scene* h, int32_t* n_nodes, int32_t* ma
     if (!h) return fail(MCPT_ERR_ARG, "null scene");
     FastBvh fb;
     if (!h->s.accel_built) return fail(MCPT_ERR_ARG, "scene was created without a host build");
-    build_fast_bvh(h->s.faces, h->s.order.data(), h->s.bi.t, fb);
+    { const Knobs k = read_knobs(); build_fast_bvh(h->s.faces, h->s.order.data(), h->s.bi.t, fb, stack_limit_for(k), build_opts_for(k)); }
     if (n_nodes) *n_nodes = int32_t(fb.nodes.size());
     if (max_depth) *max_depth = fb.max_depth;
     if (leaf_order) std::copy(fb.leaf_tris.begin(), fb.leaf_tris.end(), leaf_order);
@@ -594,6 +602,8 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     HIP_TRY(hipSetDevice(ordinal));
     std::unique_ptr<mcpt_device, void (*)(mcpt_device*)> d(new mcpt_device, mcpt_device_free);
     d->ordinal = ordinal;
+    d->knobs = read_knobs();
+    const Knobs& K = d->knobs;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipStreamCreateWithFlags(&d->look_stream, hipStreamNonBlocking));
@@ -604,7 +614,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     const mcpt_bvh_info bi = bvh_shape(t);
     d->bi = bi;
     int rc;
-    const bool talk = std::getenv("MCPT_PRINT_DIAG") != nullptr && t >= (1 << 17);
+    const bool talk = K.print_diag && t >= (1 << 17);
     const auto t_create = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (talk) std::fprintf(stderr, "device create: %s at %.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count());
@@ -718,7 +728,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     // result-identical fast structure: SAH hierarchy built on the host from the leaf order (accel_build.cpp), permuted triangle
     // copy gathered on the GPU -- or, MCPT_BUILD_DEVICE_FAST, a 4-wide tree over the Morton order built on the GPU in place
     std::shared_ptr<const FastBvh> fb_host;
-    if (!fast_on_device) { fb_host = shared_fast_bvh(h, order); lap("culling hierarchy on the host"); }
+    if (!fast_on_device) { fb_host = shared_fast_bvh(h, order, K); lap("culling hierarchy on the host"); }
     FastBvh fb_dev;                              // MCPT_BUILD_DEVICE_FAST: shape figures of the hierarchy built on this GPU
     const FastBvh& fb_ro = fast_on_device ? fb_dev : *fb_host;
     FastBvh& fb = fb_dev;
@@ -742,16 +752,14 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         // every triangle keeps its own quantised box), a SAH tree over the clusters' boxes on the host.  Sweep on MI355X
         // (MCPT_CLUSTER_LEAF x MCPT_CLUSTER_LEVELS, ms per frame synthetic 10 M SPP 16 / cornell-box): 1x1 87 / 143, 1x2 93 / 161,
         // 1x3 103 / 182, 2x1 116 / 177, 4x2 163 / 238; the host's full SAH tree: 56 / 110.
-        static const int kPerLeaf = [] { const char* e = std::getenv("MCPT_CLUSTER_LEAF"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 8 ? v : 1; }();
-        static const int kClusterLevels = [] { const char* e = std::getenv("MCPT_CLUSTER_LEVELS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 5 ? v : 1; }();
+        const int kPerLeaf = K.cluster_leaf, kClusterLevels = K.cluster_levels;
         CwNode* d_lower = nullptr;
         int n_top = 0;
         std::vector<double> top_boxes;
         bool ploc_fell_back = false;
         if (build_mode == MCPT_BUILD_DEVICE_SAH) {
             // clusters grown by locally-ordered clustering on the GPU (build_kernels.hip: device_build_ploc), the host's SAH tree over them
-            static const int kCluster = [] { const char* e = std::getenv("MCPT_PLOC_CLUSTER"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 65536 ? v : 4096; }();
-            static const int kHeightEnv = [] { const char* e = std::getenv("MCPT_PLOC_HEIGHT"); const int v = e ? std::atoi(e) : 0; return v >= 3 && v <= 24 ? v : 0; }();
+            const int kCluster = K.ploc_cluster, kHeightEnv = K.ploc_height;
             // how tall a cluster may grow: what the walk's stack leaves once the tree over the expected number of clusters has its levels
             int kHeight = kHeightEnv;
             if (!kHeight) {
@@ -760,12 +768,8 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
                 while ((1ll << lv) < est) lv++;
                 kHeight = std::max(6, std::min(20, 35 - 5 - lv));
             }
-            static const int kRadius = [] { const char* e = std::getenv("MCPT_PLOC_RADIUS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 64 ? v : 8; }();
-            static const double kAreaDen = [] { const char* e = std::getenv("MCPT_PLOC_AREA"); const double v = e ? std::atof(e) : 0; return v >= 0 && e ? v : 16.0; }();
-            static const double kCt = [] { const char* e = std::getenv("MCPT_PLOC_CT"); const double v = e ? std::atof(e) : 0; return v > 0 ? v : 1.0; }();
-            static const double kCl = [] { const char* e = std::getenv("MCPT_PLOC_CL"); return e ? std::atof(e) : 0.0; }();
-            static const int kLeaf = [] { const char* e = std::getenv("MCPT_PLOC_LEAF"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= kFastMaxLeaf ? v : kFastDefaultLeaf; }();
-            static const int kBudget = [] { const char* e = std::getenv("MCPT_PLOC_BUDGET"); const int v = e ? std::atoi(e) : 0; return v >= 3 && v <= 30 ? v : 0; }();
+            const int kRadius = K.ploc_radius, kLeaf = K.ploc_leaf ? K.ploc_leaf : kFastDefaultLeaf, kBudget = K.ploc_budget;
+            const double kAreaDen = K.ploc_area, kCt = K.ploc_ct, kCl = K.ploc_cl;
             std::vector<int32_t> top_roots;
             int lower_need = 0, rounds = 0;
             hipError_t e = device_build_ploc(d->tris, t, blo, bhi, kCluster, kHeight, kRadius, kLeaf, kAreaDen > 0 ? 1.0 / kAreaDen : 0.0, kCt, kCl, kBudget, &d_lower, &d->fast_tris, &n_cw, &n_top, &top_boxes,
@@ -846,8 +850,7 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     // 10 M-triangle scene the walk waits for memory, and a second dependent fetch per leaf (48-B record, then the 128-B record of a
     // survivor) costs more than the skipped arithmetic saves: 6.90 vs 6.44 ms per launch.  So: records only for scenes of at most
     // MCPT_PRE_TEST_MAX_TRIS triangles (default 2^20: ~200 B per triangle of nodes, records and triangles stay cache-resident).
-    long long pre_max = 1ll << 20;
-    if (const char* e = std::getenv("MCPT_PRE_TEST_MAX_TRIS")) pre_max = std::atoll(e);
+    const long long pre_max = K.pre_test_max_tris;
     if (t <= pre_max) {
         // fp32 records of the triangle phase's pre-test, one per slot of the fast triangle array
         const int n_slots = fast_on_device ? t : int(fb_ro.leaf_tris.size());
@@ -859,14 +862,14 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("pre-test records: ") + hipGetErrorString(e));
     }
     lap("culling hierarchy in HBM");
-    if (const char* e = std::getenv("MCPT_SLOW_LIST")) d->slow_cap = unsigned(std::max(1, std::atoi(e)));   // tests shrink it to force the overflow path
-    init_launch_cfg(d->cfg);
-    d->cfg.trace_pool = trace_engine_for(t) == MCPT_ENGINE_POOL ? 1 : 0;
+    if (K.slow_list) d->slow_cap = unsigned(K.slow_list);   // tests shrink it to force the overflow path
+    init_launch_cfg(d->cfg, K.logic_grid, K.trace_block_rays, K.trace_min_chunk, K.trace_max_chunk);
+    d->cfg.trace_pool = trace_engine_for(t, K) == MCPT_ENGINE_POOL ? 1 : 0;
     // the pool engine keeps the stack entries of a ray beyond those it has in LDS in an area behind the deferred-ray list of the launch
     const size_t spill_bytes = d->cfg.trace_pool ? pool_spill_bytes(d->cfg.cus) : 0;
     // ... and finishes a frame's last paths in path mode (MCPT_FINISH_ENGINE=lane: the one-lane-per-path kernel, for A/B runs)
     d->cfg.finish_pool = d->cfg.trace_pool;
-    if (const char* e = std::getenv("MCPT_FINISH_ENGINE")) { if (std::strcmp(e, "lane") == 0) d->cfg.finish_pool = 0; }
+    if (K.finish_engine == 0) d->cfg.finish_pool = 0;
     const size_t path_bytes = d->cfg.finish_pool ? finish_pool_bytes(d->cfg.cus, int(s.lights.size())) : 0;     // (0: a path's rays do not fit a lane's slots)
     if (!path_bytes) d->cfg.finish_pool = 0;
     for (auto& f : d->slot) {
@@ -882,11 +885,12 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
     HIP_TRY(hipMemset(d->aux_ctr, 0, sizeof(DCounters)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_queue), sizeof(TraceQueue)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_slow_list), size_t(d->slow_cap) * sizeof(long long) + spill_bytes));
-    if (const char* e = std::getenv("MCPT_FINISH_PATHS")) d->finish_threshold = std::atoll(e);
-    if (const char* gb = std::getenv("MCPT_WORKSPACE_GB")) {
-        const double v = std::atof(gb);
-        if (v > 0.01) d->wf_budget_bytes = size_t(v * double(size_t(1) << 30));
-    }
+    // paths left at which the finishing pass takes over: the pool form holds the wavefront kernels' pace further up (sweep on one eighth of
+    // the headline frame, ms: 250 k 14.2, 500 k 13.3, 1 M 13.1, 2 M 13.0, 4 M 13.5, 8 M 14.8; whole frame 81.0 / 80.3 at 500 k / 2 M), the
+    // one-lane-per-path form is flat from 2e5 to 1e6
+    d->finish_threshold = path_bytes ? 1500000 : 500000;
+    if (K.finish_paths >= 0) d->finish_threshold = K.finish_paths;
+    if (K.workspace_gb > 0) d->wf_budget_bytes = size_t(K.workspace_gb * double(size_t(1) << 30));
 
     DScene& S = d->ds;
     S.nodes = d->nodes; S.tris = d->tris; S.shade = d->shade; S.materials = d->materials; S.lights = d->lights;
@@ -906,11 +910,11 @@ int mcpt_device_create_ex(const mcpt_scene* h, int32_t ordinal, int32_t build_mo
         // (any prefix of the node array may be mirrored; the host builder puts the top of the tree there)
         const size_t n_cw_total = fast_on_device ? d->n_cw_nodes : fb_ro.cw.size();
         S.fast.cached = int32_t(std::min<size_t>(n_cw_total, size_t(kFastTopNodes)));
-        if (const char* e = std::getenv("MCPT_NODE_CACHE")) { const int v = std::atoi(e); if (v >= 0 && v < S.fast.cached) S.fast.cached = v; }
+        if (K.node_cache >= 0 && K.node_cache < S.fast.cached) S.fast.cached = K.node_cache;
     }
-    if (const char* e = std::getenv("MCPT_SHORT_KERNEL")) if (std::atoi(e) == 0) S.fast.stack_limit = kFastMaxDepth;
+    if (!K.short_kernel) S.fast.stack_limit = kFastMaxDepth;
     S.fast.stack_cap = S.fast.stack_limit;
-    if (const char* e = std::getenv("MCPT_TEST_STACK_CAP")) { const int v = std::atoi(e); if (v >= 4 && v < S.fast.stack_cap) S.fast.stack_cap = v; }
+    if (K.test_stack_cap >= 4 && K.test_stack_cap < S.fast.stack_cap) S.fast.stack_cap = K.test_stack_cap;
     const CameraFrame cf = camera_frame(s);
     S.cam.eye[0] = cf.eye.x; S.cam.eye[1] = cf.eye.y; S.cam.eye[2] = cf.eye.z;
     S.cam.start_point[0] = cf.start_point.x; S.cam.start_point[1] = cf.start_point.y; S.cam.start_point[2] = cf.start_point.z;
@@ -975,13 +979,13 @@ static int ensure_dirs(mcpt_device* d, hipStream_t st)
     return MCPT_OK;
 }
 
-static void counters_to_stats(const DCounters& c, mcpt_stats* s)
+static void counters_to_stats(const DCounters& c, mcpt_stats* s, bool print_diag)
 {
     s->rays_primary = c.rays_primary; s->rays_shadow = c.rays_shadow; s->rays_bounce = c.rays_bounce;
     s->node_visits = c.node_visits; s->tri_tests = c.tri_tests; s->shade_calls = c.shade_calls; s->samples = c.samples;
     s->shadow_skipped = c.shadow_skipped;
     s->dom_rays = c.trace_rays; s->dom_node_visits = c.trace_nodes; s->dom_tri_tests = c.trace_tris;
-    if (std::getenv("MCPT_PRINT_DIAG")) {
+    if (print_diag) {
         const double tot = double(c.pad[8] + c.pad[9] + c.pad[10] + c.pad[11]);
         const double iters = double(c.pad[0] + c.pad[2] + c.pad[4]);
         auto per = [](unsigned long long a, unsigned long long b) { return b ? double(a) / double(b) : 0.0; };
@@ -1066,7 +1070,7 @@ int mcpt_trace_closest(mcpt_device* d, const double* rays, int64_t n, int32_t* f
     DCounters c{};
     TRY_OR_CLEAN(hipMemcpy(&c, d->aux_ctr, sizeof c, hipMemcpyDeviceToHost));
     if (stats) {
-        counters_to_stats(c, stats);
+        counters_to_stats(c, stats, d->knobs.print_diag != 0);
         float ms = 0;
         (void)hipEventElapsedTime(&ms, d->ev[0], d->ev[1]);
         stats->ms_trace = ms; stats->ms_total = ms; stats->launches = 1;
@@ -1345,7 +1349,7 @@ static int render_device_impl(mcpt_device* d, const mcpt_render_params* p, doubl
         DCounters c{};
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(&c, f.ctr, sizeof c, hipMemcpyDeviceToHost));
-        counters_to_stats(c, stats);
+        counters_to_stats(c, stats, d->knobs.print_diag != 0);
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
         stats->ms_total = ms; stats->ms_trace = ms_trace; stats->launches = launches;
@@ -1374,7 +1378,7 @@ int mcpt_device_collect_stats(mcpt_device* d, mcpt_stats* stats)
         for (size_t i = 0; i < sizeof(DCounters) / sizeof(unsigned long long); i++) a[i] += b[i];
         sum.max_depth = std::max(sum.max_depth - c.max_depth, c.max_depth);      // a maximum, not a sum
     }
-    counters_to_stats(sum, stats);
+    counters_to_stats(sum, stats, d->knobs.print_diag != 0);
     // the bookkeeping starts over whatever the queries say: a pair that cannot be read is left out and reported
     hipError_t bad = hipSuccess;
     for (size_t i = 0; i < d->ev_used; i++) {

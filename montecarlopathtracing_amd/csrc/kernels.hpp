@@ -33,7 +33,7 @@ struct LaunchCfg {
 bool pool_engine_available();                      // wavefront.hip: the current device can hold a workgroup of the pool engine
 bool pool_engine_available_closest();              // kernels.hip: ... of its closest-hit forms
 size_t pool_spill_bytes(int cus);                  // wavefront.hip: bytes the pool engine wants behind a launch's deferred-ray list (stack entries beyond its LDS part)
-void init_launch_cfg(LaunchCfg& cfg);               // wavefront.hip (calls init_launch_cfg_closest of kernels.hip)
+void init_launch_cfg(LaunchCfg& cfg, unsigned forced_logic_grid, long long trace_block_rays, int min_chunk, int max_chunk);   // wavefront.hip (calls init_launch_cfg_closest of kernels.hip)
 void init_launch_cfg_closest(LaunchCfg& cfg);
 void launch_trace_closest(const DScene& S, bool fast, const double* d_rays, long long n, int32_t* d_face, double* d_t, double* d_p,
                           double* d_pn, DCounters* ctr, TraceQueue* queue, long long* slow_list, unsigned int slow_cap, hipStream_t st,

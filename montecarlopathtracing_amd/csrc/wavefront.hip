@@ -181,31 +181,24 @@ int persistent_grid(const void* kernel, int cus)
     return cus * per_cu;
 }
 
-// the current device's numbers (mcpt_device_create calls this once per device, with that device current)
-void init_launch_cfg(LaunchCfg& cfg)
+// the current device's numbers (mcpt_device_create calls this once per device, with that device current); forced_logic_grid,
+// trace_block_rays and the chunk bounds come from the handle's knobs (knobs.hpp)
+void init_launch_cfg(LaunchCfg& cfg, unsigned forced_logic_grid, long long trace_block_rays, int min_chunk, int max_chunk)
 {
     int dev = 0;
     hipDeviceProp_t prop;
     cfg.cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cfg.cus = prop.multiProcessorCount;
     if (cfg.cus <= 0) cfg.cus = 256;
-    const char* e = std::getenv("MCPT_LOGIC_GRID");
-    const unsigned forced = e ? unsigned(std::atoi(e)) : 0u;
-    init_launch_cfg_logic(cfg, forced);             // wavefront_logic.hip: resident grids of k_wf_logic and k_wf_finish
+    init_launch_cfg_logic(cfg, forced_logic_grid);             // wavefront_logic.hip: resident grids of k_wf_logic and k_wf_finish
     cfg.trace_grid = persistent_grid(reinterpret_cast<const void*>(k_wf_trace<MCPT_FAST_STACK, 3>), cfg.cus);
     cfg.trace_grid_short = persistent_grid(reinterpret_cast<const void*>(k_wf_trace<kFastShortStack, 4>), cfg.cus);
     // a wave that starts pays one atomic on the queue head and a few on the counters: give every block >= 2048 rays
-    e = std::getenv("MCPT_TRACE_BLOCK_RAYS");
-    long long v = e ? std::atoll(e) : 0;
-    cfg.trace_block_rays = v >= 256 ? v : 2048;
+    cfg.trace_block_rays = trace_block_rays >= 256 ? trace_block_rays : 2048;
     // every claim is an atomic on one word (~88 per microsecond on this chip): below this many rays per claim the queue head,
     // not the walk, bounds a launch of a million rays
-    e = std::getenv("MCPT_TRACE_MIN_CHUNK");
-    int c = e ? std::atoi(e) : 0;
-    cfg.min_chunk = c >= 64 ? c / 64 * 64 : 256;
-    e = std::getenv("MCPT_TRACE_MAX_CHUNK");
-    c = e ? std::atoi(e) : 0;
-    cfg.max_chunk = c >= 64 ? c / 64 * 64 : 2048;
+    cfg.min_chunk = min_chunk >= 64 ? min_chunk / 64 * 64 : 256;
+    cfg.max_chunk = max_chunk >= 64 ? max_chunk / 64 * 64 : 2048;
     if (cfg.max_chunk < cfg.min_chunk) cfg.max_chunk = cfg.min_chunk;
     cfg.trace_pool = 0;             // (mcpt_device_create picks the engine from the scene: capi.cpp: trace_engine_for)
     init_launch_cfg_closest(cfg);

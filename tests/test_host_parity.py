@@ -290,3 +290,24 @@ def test_scene_from_arrays_equals_scene_from_files(mcpt, oracle, tmp_path):
     assert deferred.info.bvh.Nr == sc.info.bvh.Nr
     with pytest.raises(mcpt.McptError):
         deferred.leaf_order()
+
+
+def test_knobs_are_read_in_one_place_and_documented(mcpt):
+    """Every environment variable of libmcpt.so is parsed by csrc/knobs.cpp into the handle that is being created (no getenv anywhere
+    else in the library, no function-local statics holding one), mcpt_knobs_describe() lists them, and INTEGRATION.md section 7 is
+    that list."""
+    import glob
+    csrc = os.path.join(ROOT, "montecarlopathtracing_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")):
+        if os.path.basename(f).startswith("knobs") or os.path.basename(f) == "build_id.cpp":
+            continue
+        assert "getenv" not in open(f).read(), f
+    table = mcpt.lib().mcpt_knobs_describe().decode()
+    names = [ln.split(" | ")[0] for ln in table.strip().split("\n")]
+    assert len(names) >= 25 and len(set(names)) == len(names) and all(n.startswith("MCPT_") for n in names)
+    src = open(os.path.join(csrc, "knobs.cpp")).read()
+    read = set(re.findall(r'"(MCPT_[A-Z0-9_]+)"', src))
+    assert read == set(names), read ^ set(names)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in names:
+        assert "`%s`" % n in doc, n
