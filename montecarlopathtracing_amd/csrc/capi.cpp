@@ -1002,9 +1002,9 @@ static void counters_to_stats(const DCounters& c, mcpt_stats* s, bool print_diag
             static const char* nm[5] = {"node", "leaf", "exact", "result", "shade"};
             const double life = double(c.pp[18]);
             for (int i = 0; i < 5; i++)
-                std::fprintf(stderr, "path pool %-6s: %10llu steps, %5.1f lanes per step, %7.0f cycles per step, %5.1f %% of wave time\n", nm[i], c.pp[i],
+                std::fprintf(stderr, "pool %-6s: %10llu steps, %5.1f lanes per step, %7.0f cycles per step, %5.1f %% of wave time\n", nm[i], c.pp[i],
                              c.pp[i] ? double(c.pp[5 + i]) / c.pp[i] : 0.0, c.pp[i] ? double(c.pp[12 + i]) / c.pp[i] : 0.0, life ? 100.0 * c.pp[12 + i] / life : 0.0);
-            std::fprintf(stderr, "path pool: %llu waves, %.0f cycles per wave, vote + claim + sleep %.1f %% of wave time, %llu sleeps, %llu steps that claimed nothing\n", c.pp[19],
+            std::fprintf(stderr, "pool: %llu waves, %.0f cycles per wave, vote + claim + sleep %.1f %% of wave time, %llu sleeps, %llu steps that claimed nothing\n", c.pp[19],
                          life / c.pp[19], life ? 100.0 * c.pp[17] / life : 0.0, c.pp[10], c.pp[11]);
         }
         for (int i = 0; i < 4; i++) std::fprintf(stderr, "pool class %d: %llu steps, %.1f lanes per step (%.1f could before the claim)\n", i, c.dbg[8 + i], c.dbg[8 + i] ? double(c.dbg[12 + i]) / c.dbg[8 + i] : 0.0, c.dbg[8 + i] ? double(c.dbg[16 + i]) / c.dbg[8 + i] : 0.0);
@@ -1191,7 +1191,7 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
     WfState A, B;
     if (!wf_carve(f.wf_ws, f.wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
     a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = f.hit_slots; a.surf = f.surf; a.alive_base = f.alive_base; a.hits = f.hits;
-    a.dirs = d->dirs; a.rad = f.rad; a.counts = f.wf_counts; a.ctr = f.ctr; a.tris = d->tris;
+    a.dirs = d->dirs; a.rad = f.rad; a.counts = f.wf_counts; a.ctr = f.ctr; a.tris = d->tris; a.queue = fast ? f.queue : nullptr;
     a.finish_below = fast ? unsigned(std::min<long long>(std::max<long long>(d->finish_threshold, 0), 1ll << 30)) : 0u;
     // Iterations are enqueued without waiting for their counts: every kernel reads its input count from the device slot the
     // previous one wrote.  The host looks at a count only every few iterations (to stop, and to size the next grids).

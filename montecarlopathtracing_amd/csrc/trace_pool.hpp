@@ -83,6 +83,9 @@ struct NoPaths { static constexpr bool kPaths = false; };
 #define MCPT_POOL_CLAIM_ORDER __ATOMIC_RELAXED
 #define MCPT_POOL_FILE_ORDER __ATOMIC_RELAXED
 #endif
+#ifndef MCPT_POOL_FASTPUSH
+#define MCPT_POOL_FASTPUSH 1        /* 0: a branch per pushed child (A/B runs) */
+#endif
 #ifndef MCPT_PW_INNER
 #define MCPT_PW_INNER 4
 #endif
@@ -250,7 +253,13 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         int sp = spf & 255;
         if (sp == 0) return C_FIN;
         sp--;
+#if MCPT_POOL_FASTPUSH
+        int nxt;
+        if (!__ballot(sp >= SCAP)) nxt = L.stack[(sp * KT + k) * 64 + lane];
+        else nxt = st_get(sp, k);
+#else
         const int nxt = st_get(sp, k);
+#endif
         const bool node = nxt >= 0;
         const int ref = -1 - nxt;
         const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
@@ -385,13 +394,44 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
                     rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
                     rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
+#if MCPT_POOL_CACHE_N
                     const CwHits h = cw_step(nodes, cur, ncache, rf, limit);
+#else
+                    const CwHits h = cw_step(nodes + cur, rf, limit);        // (a global load: a pointer that may be LDS or memory is a flat one)
+#endif
                     junk += pf; pf = 0;
+#if MCPT_POOL_FASTPUSH
+                    // The children come back sorted with the culled ones last: n hits, the n - 1 farther ones go on the stack, farthest
+                    // first.  When every lane's pushes stay in the LDS part of its stack (nine steps in ten) they are three predicated
+                    // stores at computed positions -- no branch per push, none between LDS and the spill area.
+                    const int n_hit = (h.ref[0] != MCPT_FAST_EMPTY) + (h.ref[1] != MCPT_FAST_EMPTY) + (h.ref[2] != MCPT_FAST_EMPTY) + (h.ref[3] != MCPT_FAST_EMPTY);
+                    if (!__ballot(sp + n_hit - 1 > SCAP)) {
+                        int* const col = &L.stack[k * 64 + lane];
+                        if (n_hit >= 4) col[sp * (KT * 64)] = h.ref[3];
+                        if (n_hit >= 3) col[(sp + n_hit - 3) * (KT * 64)] = h.ref[2];
+                        if (n_hit >= 2) col[(sp + n_hit - 2) * (KT * 64)] = h.ref[1];
+                        sp += n_hit > 1 ? n_hit - 1 : 0;
+                    } else {
+                        if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
+                        if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
+                        if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
+                    }
+#else
                     if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
                     if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
                     if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
+#endif
                     int nxt = h.ref[0];
+#if MCPT_POOL_FASTPUSH
+                    {
+                        const bool pop = nxt == MCPT_FAST_EMPTY && sp > 0;
+                        if (pop) sp--;
+                        if (!__ballot(pop && sp >= SCAP)) { if (pop) nxt = L.stack[(sp * KT + k) * 64 + lane]; }      // (an LDS read, not a flat one)
+                        else if (pop) nxt = st_get(sp, k);
+                    }
+#else
                     if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = st_get(sp, k); }
+#endif
                     const bool node = nxt >= 0, none = nxt == MCPT_FAST_EMPTY;
                     const int ref = -1 - nxt;
                     const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
@@ -846,6 +886,12 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         }
     } else
     if (lane == 0 && w.dbg) {
+        {   // (the same account for the trace launches: DCounters::pp follows DCounters::dbg)
+            unsigned long long* o = w.dbg + 24;
+            for (int i = 0; i < 4; i++) { atomicAdd(&o[i], d_cs[i]); atomicAdd(&o[5 + i], d_cl[i]); atomicAdd(&o[12 + i], d_cyc[i]); }
+            atomicAdd(&o[10], d_sleep); atomicAdd(&o[11], d_miss); atomicAdd(&o[17], d_cyc[5]);
+            atomicAdd(&o[18], __builtin_amdgcn_s_memtime() - d_t0); atomicAdd(&o[19], 1ull);
+        }
         atomicAdd(&w.dbg[0], d_used); atomicAdd(&w.dbg[1], d_okc); atomicAdd(&w.dbg[2], d_steps); atomicAdd(&w.dbg[3], d_kill); atomicAdd(&w.dbg[6], d_tickets);
         atomicAdd(&w.dbg[7], (unsigned long long)c_rays);
         for (int i = 0; i < 4; i++) { atomicAdd(&w.dbg[8 + i], d_cs[i]); atomicAdd(&w.dbg[12 + i], d_cl[i]); atomicAdd(&w.dbg[16 + i], d_want[i]); }

@@ -227,7 +227,7 @@ void launch_wf_trace(const DScene& S, const WfArgs& a, long long n_upper, bool f
     const int resident = shallow ? cfg.trace_grid_short : cfg.trace_grid;
     const long long blocks_needed = (total + cfg.trace_block_rays - 1) / cfg.trace_block_rays;
     const int g = (int)(blocks_needed < resident ? blocks_needed : resident);
-    (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);
+    if (a.queue != queue) (void)hipMemsetAsync(queue, 0, sizeof(TraceQueue), st);      // (else the logic pass before this launch has cleared it)
     if (cfg.trace_pool && total < (1ll << 32)) {        // (the pool engine keeps a ray's slot number in 32 bits)
         const long long per_block = cfg.trace_block_rays * (MCPT_POOL_WAVES / 4);
         const long long nb = (total + per_block - 1) / per_block;

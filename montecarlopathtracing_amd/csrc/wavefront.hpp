@@ -88,6 +88,8 @@ struct WfArgs {
     // Hand-over to the finishing kernel, decided on the device: when logic(d) leaves at most this many paths, k_wf_finish
     // (launched after every logic pass) runs them to their end and trace(d), logic(d+1), ... find nothing to do.  0 = never.
     unsigned int finish_below;
+    TraceQueue* queue;          // the frame slot's queue words: k_wf_logic clears them for the trace launch that follows it (a fill dispatch per
+                                // iteration, ~13 us with its gap, is a percent of a rank's share of the frame)
 };
 
 size_t wf_bytes_per_path(int nl);

@@ -36,6 +36,7 @@ template <bool FIRST>
 __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a)
 {
     const long long n_prev = (long long)a.counts_in->n_next * a.count_mul;
+    if (a.queue && blockIdx.x == 0 && threadIdx.x == 0) { a.queue->head = 0ull; a.queue->slow_count = 0u; a.queue->redo_all = 0u; }   // for trace(depth)
     if (!FIRST && n_prev <= (long long)a.finish_below) return;         // those paths went to k_wf_finish
     // (two sets, used in turn: the values of one block iteration are still being read by its slower waves while the faster ones
     // write the next iteration's -- with one set that took a third barrier per iteration)

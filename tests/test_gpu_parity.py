@@ -424,8 +424,11 @@ def test_pre_test_rejects_no_candidate(tmp_path):
     import re
     import subprocess
     import sys
+    import glob
     lib = os.path.join(ROOT, "montecarlopathtracing_amd", "csrc", "variants", "libmcpt_chk.so")
-    if not os.path.exists(lib):
+    csrc = os.path.join(ROOT, "montecarlopathtracing_amd", "csrc")
+    newest = max(os.path.getmtime(f) for pat in ("*.cpp", "*.hip", "*.hpp") for f in glob.glob(os.path.join(csrc, pat)) if not f.endswith("build_id.cpp"))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < newest:        # (build() makes it; a stale one is rebuilt here: hipcc is on the GPU box too)
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "chk", "-DMCPT_PRE_CHECK"], stdout=subprocess.DEVNULL)
     code = r'''
 import os, sys
