@@ -148,7 +148,7 @@ def cpu_baseline(scene_dir, name, seed, target_seconds=15.0, frame_spp=256):
         osc.render_reference_style(frame_spp, seed, rs * 4, cs * 4, stats=sr0, img=img)
         dtr0 = max(time.time() - t0, 1e-3)
         # (the calibration lattice is a sixteenth of the timed one)
-        scale = max(1.0, min(16.0, (target_seconds / 3.0) / (dtr0 * 16.0)))
+        scale = max(1.0, min(16.0, (target_seconds / 2.0) / (dtr0 * 16.0)))
         rs2 = max(8, int(rs / scale ** 0.5)); cs2 = max(8, int(cs / scale ** 0.5))
         sr = O.Stats()
         t0 = time.time()

@@ -255,7 +255,8 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         sp--;
 #if MCPT_POOL_FASTPUSH
         int nxt;
-        if (!__ballot(sp >= SCAP)) nxt = L.stack[(sp * KT + k) * 64 + lane];
+        // (the empty asm keeps the compiler from merging the two reads into one flat load through a selected address)
+        if (!__ballot(sp >= SCAP)) { nxt = L.stack[(sp * KT + k) * 64 + lane]; __asm__ volatile("" : "+v"(nxt)); }
         else nxt = st_get(sp, k);
 #else
         const int nxt = st_get(sp, k);
@@ -426,7 +427,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     {
                         const bool pop = nxt == MCPT_FAST_EMPTY && sp > 0;
                         if (pop) sp--;
-                        if (!__ballot(pop && sp >= SCAP)) { if (pop) nxt = L.stack[(sp * KT + k) * 64 + lane]; }      // (an LDS read, not a flat one)
+                        if (!__ballot(pop && sp >= SCAP)) { if (pop) { nxt = L.stack[(sp * KT + k) * 64 + lane]; __asm__ volatile("" : "+v"(nxt)); } }      // (an LDS read, not a flat one)
                         else if (pop) nxt = st_get(sp, k);
                     }
 #else

@@ -4,7 +4,7 @@
 # bench line (with CPU baseline), rocprofv3 kernel stats of the same command, FETCH_SIZE / WRITE_SIZE and the SQ / TCP sets in
 # separate --pmc passes, kernel timelines at N = 1 and at one eighth of the frame, per-rank share at N = 2, 4, 8 (--sim-world),
 # the other configs (3, 4 and 5 at their own size).
-set -e
+set +e
 tag=${1:-final}
 root=$(pwd)
 out=$root/gpurun_out/$tag
@@ -60,7 +60,7 @@ other_pmc synthetic10m $KS "--scene synthetic --spp 16"
 # lanes per phase, iterations and the pre-test's share from the in-kernel counters (diagnostic build: variants/libmcpt_diag.so, tools/build_variant.sh diag "-DMCPT_TRACE_DIAG -DMCPT_POOL_DEBUG")
 if [ -f montecarlopathtracing_amd/csrc/variants/libmcpt_diag.so ]; then
   MCPT_LIB=montecarlopathtracing_amd/csrc/variants/libmcpt_diag.so MCPT_PRINT_DIAG=1 timeout -k 10 200 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/diag.json 2> $out/diag.err
-  grep -E "trace diag|k_wf_trace:|deferred|logic diag|finish diag|pool class|pool:" $out/diag.err | tail -10 > $out/trace_phases.txt
+  grep -E "trace diag|k_wf_trace:|deferred|logic diag|finish diag|^pool " $out/diag.err | tail -24 > $out/trace_phases.txt
   cat $out/trace_phases.txt
 fi
 for f in veach_mis_spp100 interior_spp256 synthetic10m_spp16 synthetic10m_3840x2160_spp1024; do python3 -c "import json; d=json.load(open('$out/$f.json')); print('$f', round(d['ms_per_step'],2), 'ms', round(d['value'],1), 'Mrays/s', round(d['nodes_per_ray'],1), round(d['tris_per_ray'],1))"; done
