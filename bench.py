@@ -11,8 +11,11 @@ Prints ONE JSON line (last line of stdout) on rank 0.  Two ways to drive N GPUs,
       what a caller of render_scene() (MTPC/MTPC.cpp:35-68) gets.  No torch in the process: libmcpt.so runs on the HIP runtime it
       was built against.  Fewer visible GPUs than N: exit code 2.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-      one process per GPU (RANK / WORLD_SIZE in the environment, or --launcher torch): every rank renders its tiles with
-      mcpt_render_device, torch.distributed (backend nccl = RCCL) gathers them (montecarlopathtracing_amd/dist.py).
+      one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment: --launcher procs): every rank renders its tiles with
+      mcpt_render_device and the ranks gather them into rank 0's HBM over an RCCL communicator they build themselves (mcpt_comm_*,
+      montecarlopathtracing_amd/procs.py) -- the launcher only starts the processes; torch is NOT imported by the ranks, so they too
+      run on the HIP runtime the library was built against (a process that imports torch gets the wheel's: DESIGN.md 8a).
+      --launcher torch: the older form, torch.distributed (backend nccl = RCCL) gathers (montecarlopathtracing_amd/dist.py).
 
 Every N renders one frame at a time (frames_in_flight 1: a step's time is a frame's latency); --pipeline (one GPU, diagnostic)
 keeps two frames in flight on two streams.
@@ -293,6 +296,76 @@ def run_capi(args):
             "build_id": M.build_id(), "launch_ranks": n_ranks_timed, "M": M, "engine": scene.trace_engine()}
 
 
+def run_procs(args):
+    """One process per GPU under a launcher (torch.distributed.run sets RANK / WORLD_SIZE / LOCAL_RANK), WITHOUT torch in the process:
+    every rank renders its tiles with its own mcpt_device on the HIP runtime libmcpt.so was compiled against, the frames are gathered
+    into rank 0's HBM over an RCCL communicator the ranks build themselves (mcpt_comm_*, montecarlopathtracing_amd/procs.py), the timed
+    region is bracketed by that communicator's barrier and a stream synchronisation, and the time is the maximum over the ranks."""
+    import numpy as np
+    import montecarlopathtracing_amd as M
+    from montecarlopathtracing_amd.procs import ProcessGroup, launch_env
+    t_start = time.time()
+    rank, world, local_rank = launch_env()
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if M.device_count() <= local_rank:
+        print("bench.py: rank %d wants GPU %d, %d visible" % (rank, local_rank, M.device_count()), file=sys.stderr)
+        sys.exit(2)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hip_rt
+    pg = ProcessGroup(local_rank, rank, world, started=t_start)
+    scene, scene_dir, build_mode = make_scene(M, args, talk=rank == 0)
+    dev = M.Device(scene, local_rank, build=build_mode)
+    H, W = dev.height, dev.width
+    frame_buf = hip_rt.DeviceBuffer(H * W * 24)
+    stream = hip_rt.Stream()
+    flags = M.RENDER_KEEP_STATS
+
+    def frame():
+        dev.render_device(frame_buf.ptr.value, args.spp, args.seed, rank, world, args.tile_w, args.tile_h, flags=flags, stats=None, stream=stream.h.value)
+        pg.gather_frame(scene, frame_buf.ptr.value, args.tile_w, args.tile_h, stream=stream.h.value)      # (returns when this rank's part is done)
+
+    def sync():
+        stream.synchronize()
+        pg.barrier()
+        stream.synchronize()
+
+    for _ in range(args.warmup):
+        frame()
+    sync()
+    dev.collect_stats()
+    st = M.Stats()
+    tot = {k: 0 for k in COUNT_KEYS}
+    tot["ms_trace"] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    sync()
+    elapsed = time.perf_counter() - t0
+    dev.collect_stats(st)
+    add_stats(tot, st)
+    mx = pg.allreduce([elapsed, tot["ms_trace"]], op="max")
+    sm = pg.allreduce([float(tot[k]) for k in COUNT_KEYS], op="sum")
+    elapsed, tot["ms_trace"] = float(mx[0]), float(mx[1])
+    for i, k in enumerate(COUNT_KEYS):
+        tot[k] = float(sm[i])
+    frame_host = None
+    if args.save_png and rank == 0:
+        frame_host = np.zeros((H, W, 3))
+        frame_buf.to_host_async(frame_host, stream.h)
+        stream.synchronize()
+    comm_ranks = pg.size()
+    pg.barrier()
+    pg.close()
+    if rank != 0:
+        sys.exit(0)
+    extra = {"launcher": "procs: one process per GPU, mcpt_render_device per rank, gather over an RCCL communicator of the processes (mcpt_comm_*); no torch in the process",
+             "hip_runtime": M.hip_runtime_path(), "rccl_ranks": comm_ranks, "gather": "rccl", "frames_in_flight": 1}
+    return {"elapsed": elapsed, "tot": tot, "world": world, "scene": scene, "scene_dir": scene_dir, "frame": frame_host, "extra": extra,
+            "build_id": M.build_id(), "launch_ranks": world, "M": M, "engine": scene.trace_engine()}
+
+
 def run_torch(args):
     """One process per GPU under torch.distributed.run: mcpt_render_device per rank, torch.distributed gather (dist.py)."""
     import torch
@@ -381,8 +454,9 @@ def main():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--launcher", default="auto", choices=["auto", "capi", "torch"],
-                    help="auto: torch when started by torch.distributed.run (WORLD_SIZE set), else capi (one process, mcpt_multi_*)")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "capi", "procs", "torch"],
+                    help="auto: procs when started by torch.distributed.run (RANK / WORLD_SIZE set: one process per GPU, RCCL communicator of the "
+                         "processes, no torch in them), else capi (one process, mcpt_multi_*); torch: the ranks gather through torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="size of the CPU baseline's bounded sample")
     ap.add_argument("--save-png", default=None)
@@ -404,8 +478,8 @@ def main():
 
     launcher = args.launcher
     if launcher == "auto":
-        launcher = "torch" if int(os.environ.get("WORLD_SIZE", "0")) >= 1 and "RANK" in os.environ else "capi"
-    res = run_torch(args) if launcher == "torch" else run_capi(args)
+        launcher = "procs" if int(os.environ.get("WORLD_SIZE", "0")) >= 1 and "RANK" in os.environ else "capi"
+    res = run_torch(args) if launcher == "torch" else (run_procs(args) if launcher == "procs" else run_capi(args))
     M = res["M"]
     tot, elapsed, world, scene_dir, scene = res["tot"], res["elapsed"], res["world"], res["scene_dir"], res["scene"]
     steps = max(1, args.steps)

@@ -253,6 +253,23 @@ int  mcpt_multi_collect_stats(mcpt_multi*, mcpt_stats* stats);
 int  mcpt_multi_last_timing(const mcpt_multi*, double* render_ms, double* gather_ms, int32_t* comm_ranks);
 void mcpt_multi_free(mcpt_multi*);
 
+/* ---- one process per GPU (since 105; no reference counterpart) ---- */
+/* The same exchange between the PROCESSES of a launch: every rank is a process that drives one GPU through mcpt_device_* (params->rank /
+ * world = its place in the launch), and at the end of a frame the ranks' pixels travel over an RCCL communicator into rank 0's frame.
+ * Rank 0 asks mcpt_comm_unique_id for RCCL's 128-byte id and hands it to the other ranks by whatever channel the launcher offers
+ * (montecarlopathtracing_amd/procs.py: a file keyed by the launcher's process id); every rank then calls mcpt_comm_create.  No torch in
+ * the process: the ranks run on the HIP runtime libmcpt.so was compiled against (see mcpt_hip_runtime_check) and /opt/rocm's librccl.
+ *   mcpt_comm_gather_frame: d_frame = this rank's frame on its GPU (H*W*3 doubles, only its own pixels written); on return rank 0's holds
+ *                           every pixel.  tile_w / tile_h of params select the partition; stream = the stream the frame was rendered on.
+ *   mcpt_comm_allreduce   : v[n <= 64] on the host, summed (op 0) or maximised (op 1) over the ranks in place; n = 0: a barrier. */
+typedef struct mcpt_comm mcpt_comm;
+int  mcpt_comm_unique_id(uint8_t* id, int64_t cap /* >= 128 */);          /* returns the number of bytes written (128) or an error */
+int  mcpt_comm_create(int32_t device_ordinal, int32_t rank, int32_t world, const uint8_t* id, int64_t id_bytes, mcpt_comm** out);
+int  mcpt_comm_size(const mcpt_comm*);                                     /* ranks the RCCL communicator reports */
+int  mcpt_comm_gather_frame(mcpt_comm*, const mcpt_scene*, const mcpt_render_params*, double* d_frame, void* stream);
+int  mcpt_comm_allreduce(mcpt_comm*, double* v, int32_t n, int32_t op);
+void mcpt_comm_free(mcpt_comm*);
+
 /* ---- output (imshow + svpng) ---- */
 int  mcpt_quantize_rgb8(const double* img, int64_t n, uint8_t* rgb8);        /* (unsigned char)clamp(v*255,0,255) */
 int  mcpt_write_png(const char* file, const uint8_t* rgb8, int32_t width, int32_t height);

@@ -78,6 +78,7 @@ EXPORTS = [
     "mcpt_quantize_rgb8", "mcpt_write_png", "mcpt_png_encode", "mcpt_png_encode_deflate", "mcpt_write_png_deflate", "mcpt_write_pfm",
     "mcpt_checkpoint_save", "mcpt_checkpoint_load", "mcpt_decode_jpeg",
     "mcpt_multi_create", "mcpt_multi_num_devices", "mcpt_multi_render", "mcpt_multi_render_device", "mcpt_multi_last_timing", "mcpt_multi_collect_stats", "mcpt_multi_free",
+    "mcpt_comm_unique_id", "mcpt_comm_create", "mcpt_comm_size", "mcpt_comm_gather_frame", "mcpt_comm_allreduce", "mcpt_comm_free",
     "mcpt_render_scene", "mcpt_render_scene_ex", "mcpt_render_scene_opts",
 ]
 
@@ -160,6 +161,13 @@ def lib():
     L.mcpt_multi_collect_stats.argtypes = [P, C.POINTER(Stats)]
     L.mcpt_multi_free.argtypes = [P]
     L.mcpt_multi_free.restype = None
+    L.mcpt_comm_unique_id.argtypes = [U8, C.c_int64]
+    L.mcpt_comm_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, U8, C.c_int64, C.POINTER(P)]
+    L.mcpt_comm_size.argtypes = [P]
+    L.mcpt_comm_gather_frame.argtypes = [P, P, C.POINTER(RenderParams), P, P]
+    L.mcpt_comm_allreduce.argtypes = [P, D, C.c_int32, C.c_int32]
+    L.mcpt_comm_free.argtypes = [P]
+    L.mcpt_comm_free.restype = None
     L.mcpt_render_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     L.mcpt_render_scene_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(RenderSceneOptions), C.POINTER(Stats)]
     L.mcpt_render_scene_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(RenderSceneOptions), C.c_int64, C.POINTER(Stats)]

@@ -55,3 +55,39 @@ def test_gather_assembles_the_frame(world, tmp_path):
     frame = np.load(tmp_path / "frame.npy")
     full = np.load(tmp_path / "full.npy")
     assert np.array_equal(frame.view(np.uint64), full.view(np.uint64))
+
+
+def _rdzv_worker(rank, world, path, out):
+    import montecarlopathtracing_amd.procs as P
+    ident = P.exchange_id(rank, world, lambda: bytes(range(128)), path, timeout=30.0)
+    out.put((rank, ident))
+
+
+def test_unique_id_rendezvous_between_processes(tmp_path):
+    """What the one-process-per-GPU launcher form needs besides RCCL itself (montecarlopathtracing_amd/procs.py; no torch, no GPU): rank 0
+    publishes the 128-byte unique id atomically under a name every rank of a launch derives for itself, the others wait for it; a
+    record left behind by an earlier launch under the same name is not taken for this one's."""
+    import multiprocessing as mp
+    import time
+    import numpy as np
+    import montecarlopathtracing_amd.procs as P
+    path = str(tmp_path / "rdzv")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, 3, path, q)) for r in (2, 1, 0)]       # (the readers start first)
+    for p_ in procs[:2]:
+        p_.start()
+    time.sleep(0.3)
+    procs[2].start()
+    got = dict(q.get(timeout=60) for _ in range(3))
+    for p_ in procs:
+        p_.join(30)
+    assert got[0] == got[1] == got[2] == bytes(range(128))
+    # a stale record (ten minutes old) is ignored until rank 0 writes a fresh one
+    with open(path, "wb") as fh:
+        fh.write(np.float64(time.time() - 600.0).tobytes() + bytes(128))
+    import pytest
+    with pytest.raises(TimeoutError):
+        P.exchange_id(1, 2, None, path, timeout=0.3)
+    assert P.exchange_id(0, 1, lambda: b"x" * 128, path) == b"x" * 128                            # a launch of one needs no file
+    assert P.rendezvous_file("abc").endswith("mcpt_rdzv_abc")

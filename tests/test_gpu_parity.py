@@ -376,6 +376,40 @@ def test_pool_engine_equals_voting_engine(pair, mcpt, monkeypatch):
         dp.close()
 
 
+def test_finishing_pass_in_pool_form_equals_the_lane_form(pair, mcpt, monkeypatch):
+    """The finishing pass exists in two forms: one lane per path in lock-step (k_wf_finish: what scenes of the voting engine run) and the
+    pool engine in path mode (k_wf_finish_pool, trace_pool.hpp with PP::kPaths: a workgroup owns the paths its LDS-resident rays belong
+    to, SHADE is a step class, no ray goes through memory; what small scenes run from 1.5 M paths down).  Same vertex functions, same
+    tests on the same triangles: whole frames must be equal bit for bit -- to each other and to the megakernel -- with the same counts,
+    whether the pass takes every path straight after the first logic pass (small frames), takes over late (hand-over forced down to
+    2 000 paths) or adopts more paths than its path slots hold at once (one light: 640 per CU; the 160x90 SPP-32 frame hands over
+    ~400 k).  Covers one, two and five lights (cornell-box, glassroom / interior, veach-mis: 10, 6 and 3 path slots per lane)."""
+    name, osc, sc, dev0 = pair
+    monkeypatch.setenv("MCPT_FINISH_ENGINE", "lane")
+    lane = mcpt.Device(sc, 0)
+    monkeypatch.delenv("MCPT_FINISH_ENGINE")
+    pool = mcpt.Device(sc, 0)
+    monkeypatch.setenv("MCPT_FINISH_PATHS", "2000")
+    late = mcpt.Device(sc, 0)
+    try:
+        for spp in (1, 8, 32):
+            sl, sp, sa = mcpt.Stats(), mcpt.Stats(), mcpt.Stats()
+            a = lane.generateImg(spp, seed=3, stats=sl)
+            b = pool.generateImg(spp, seed=3, stats=sp)
+            c = late.generateImg(spp, seed=3, stats=sa)
+            m = pool.generateImg(spp, seed=3, flags=mcpt.RENDER_MEGAKERNEL)
+            assert np.array_equal(_bits(a), _bits(b)), "%d channels differ between the two forms" % int((_bits(a) != _bits(b)).sum())
+            assert np.array_equal(_bits(b), _bits(c)) and np.array_equal(_bits(b), _bits(m))
+            for s in (sp, sa):
+                assert (s.rays_shadow, s.rays_bounce, s.shade_calls, s.shadow_skipped, s.max_depth) == \
+                       (sl.rays_shadow, sl.rays_bounce, sl.shade_calls, sl.shadow_skipped, sl.max_depth)
+            assert sp.launches <= sa.launches          # (the late hand-over runs more wavefront iterations)
+        assert a.sum() > 0
+    finally:
+        for d in (lane, pool, late):
+            d.close()
+
+
 def _gpu_emitter_map(mcpt, sc, dev):
     """[H, W] bool from the product's own frame: at SPP 1 a pixel whose primary hit is an emitter holds the light's radiance
     exactly -- rounded to float, the accumulator is a glm::vec3 (pathTracing.cpp:141-144, :301; k_primary_dirs -> primary hits
@@ -831,6 +865,51 @@ def test_bench_line_keeps_its_contract(tmp_path):
     rs = c["reference_style"]
     assert rs["threads"] == 8 and rs["value"] > 0 and rs["unit"] == "Mrays/s" and "pathTracing.cpp:300-320" in rs["sample"]
     assert rs["value"] < c["value"]             # <= 8 threads and a fork/join per pixel against every core of the socket
+
+
+def test_one_process_per_gpu_without_torch(mcpt, tmp_path):
+    """The launcher form of N GPUs: `python -m torch.distributed.run ... bench.py --gpus N` starts one process per GPU, and the ranks
+    gather their frames over an RCCL communicator they build themselves (mcpt_comm_*, montecarlopathtracing_amd/procs.py) -- torch
+    is not imported by them, so they pass the runtime gate like every other caller.  On the one-GPU test box: a launch of one (the
+    communicator of one rank, its all-reduce and barrier, the gather that has nothing to move) through bench.py under the launcher's
+    environment, and through the class directly; the frame equals the plain one-GPU frame."""
+    import json
+    import subprocess
+    import sys
+    from montecarlopathtracing_amd.procs import ProcessGroup
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512")
+    png = str(tmp_path / "procs.png")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180",
+                          "--spp", "8", "--no-cpu-baseline", "--save-png", png], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["config"]["launcher"].startswith("procs") and d["rccl_ranks"] == 1 and "torch" not in d["hip_runtime"] and d["n_gpus"] == 1
+    assert d["value"] > 0 and d["config"]["frames_in_flight"] == 1
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--width", "320", "--height", "180", "--spp", "8",
+                            "--no-cpu-baseline", "--save-png", str(tmp_path / "plain.png")], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    assert open(png, "rb").read() == open(str(tmp_path / "plain.png"), "rb").read()
+    # the class itself, in this process
+    pg = ProcessGroup(0, rank=0, world=1)
+    try:
+        assert pg.size() == 1
+        v = pg.allreduce([1.5, -2.0, 7.0], op="sum")
+        assert list(v) == [1.5, -2.0, 7.0] and list(pg.allreduce([3.0], op="max")) == [3.0]
+        pg.barrier()
+        sc = mcpt.Scene(SCENES, "cornell-box", width=64, height=36)
+        dev = mcpt.Device(sc, 0)
+        import hip_rt
+        buf = hip_rt.DeviceBuffer(64 * 36 * 24)
+        st = hip_rt.Stream()
+        dev.render_device(buf.ptr.value, 2, 5, 0, 1, 0, 0, flags=0, stats=None, stream=st.h.value)
+        pg.gather_frame(sc, buf.ptr.value, stream=st.h.value)
+        got = np.zeros((36, 64, 3))
+        buf.to_host_async(got, st.h)
+        st.synchronize()
+        assert np.array_equal(_bits(got), _bits(dev.generateImg(2, seed=5)))
+        buf.free(); st.destroy(); dev.close(); sc.close()
+    finally:
+        pg.close()
 
 
 def test_bench_refuses_more_gpus_than_visible_and_quotes_only_profiles_of_the_loaded_build(mcpt, tmp_path):

@@ -15,7 +15,7 @@ for f in kernels wavefront build_kernels; do
   $HIPCC $base $hip_only --offload-arch=gfx950 -c -o variants/obj_$name/$f.o $f.hip &
 done
 $HIPCC $base $hip_only $logic_flags --offload-arch=gfx950 -c -o variants/obj_$name/wavefront_logic.o wavefront_logic.hip &
-for f in capi knobs scene_loader bvh_build accel_build png_writer output_formats jpeg_decoder multi_device; do
+for f in capi knobs scene_loader bvh_build accel_build png_writer output_formats jpeg_decoder multi_device proc_comm; do
   [ -f $f.cpp ] && g++ $base -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c -o variants/obj_$name/$f.o $f.cpp &
 done
 # mcpt_build_id() of a variant: the Makefile's recipe (sources + flags + arch) with this variant's extra flags, so that a variant never
