@@ -45,6 +45,17 @@ bool wf_carve(void* base, size_t bytes, long long cap, int nl, WfState& A, WfSta
 }
 
 // ---------------------------------------------------------------------------------------------- trace kernels
+#ifndef MCPT_KARG_SOURCE
+#define MCPT_KARG_SOURCE 1          /* the trace kernels read WfArgs from the kernarg segment where they need it (wf_ray_source.hpp: WfRaySourceK); 0: held in registers */
+#endif
+// where the second kernel parameter (WfArgs a) of k_wf_trace / k_wf_trace_pool lies in the kernarg segment: explicit arguments are laid
+// out in order at their natural alignment, DScene first
+__device__ __forceinline__ WfArgsKernarg wf_kernarg_args()
+{
+    constexpr size_t off = (sizeof(DScene) + alignof(WfArgs) - 1) / alignof(WfArgs) * alignof(WfArgs);
+    typedef const char __attribute__((address_space(4)))* kbytes;
+    return (WfArgsKernarg)((kbytes)__builtin_amdgcn_kernarg_segment_ptr() + off);
+}
 
 // persistent fast walk
 __device__ __forceinline__ long long wf_chunk(long long total, int min_chunk, int max_chunk)
@@ -65,7 +76,11 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_trace(DScene S, WfArgs a, Tra
     const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk, max_chunk);
     __shared__ int lds_stack[STACK * 256];
     __shared__ double lds_rays[4 * MCPT_RAYBUF_BYTES / 8];
+#if MCPT_KARG_SOURCE
+    WfRaySourceK src; src.ap = wf_kernarg_args(); src.n_paths = n_paths; src.nl = a.nl;
+#else
     WfRaySource src; src.a = a; src.n_paths = n_paths;
+#endif
     LaneStats ls;
     Work w = {0, 0};
 #ifdef MCPT_PRE_CHECK
@@ -95,13 +110,19 @@ __global__ void __launch_bounds__(NW * 64, 1) k_wf_trace_pool(DScene S, WfArgs a
     if (n_paths <= (long long)a.finish_below) return;
     const long long chunk = wf_chunk(n_paths * (a.nl + 1), min_chunk, max_chunk);
     __shared__ PoolLds<NW, KT, SCAP> L;
-    WfRaySource src; src.a = a; src.n_paths = n_paths;
+#if MCPT_KARG_SOURCE
+    typedef WfRaySourceK Src;
+    Src src; src.ap = wf_kernarg_args(); src.n_paths = n_paths; src.nl = a.nl;
+#else
+    typedef WfRaySource Src;
+    Src src; src.a = a; src.n_paths = n_paths;
+#endif
     LaneStats ls;
     Work w = {0, 0};
 #ifdef MCPT_POOL_DEBUG
     if (a.ctr) w.dbg = a.ctr->dbg;
 #endif
-    trace_pool<WfRaySource, NW, KT, SCAP>(S, src, queue, slow_list, slow_cap, chunk, L, w, reinterpret_cast<int*>(slow_list + slow_cap));
+    trace_pool<Src, NW, KT, SCAP>(S, src, queue, slow_list, slow_cap, chunk, L, w, reinterpret_cast<int*>(slow_list + slow_cap));
     ls.nodes = w.nodes; ls.tris = w.tris;
     if (a.ctr) {
         const unsigned long long tn = wave_sum(w.nodes), tt = wave_sum(w.tris), tr = wave_sum(w.rays), te = wave_sum(w.exact);

@@ -53,4 +53,62 @@ struct WfRaySource {
     }
 };
 
+// The same source reading the launch's arguments where the runtime put them -- the kernarg segment -- each time a ray is fetched or
+// stored, instead of holding them in scalar registers for the length of the kernel.  A trace kernel keeps ~25 pointers and a dozen
+// scalars of WfArgs alive across its walk loop although only the refill / store section (one step in nine) looks at them; with the
+// loop's own uniform state that is more than the 102 SGPRs a wave has, and the excess lives in VGPR lanes (29 spilled SGPRs in the
+// pool kernel, 49 in the voting engine's: 172 v_readlane_b32 in its ISA, each with its wait states, several of them in the node step).
+// Scalar loads from the kernarg segment hit the scalar cache; the empty asm keeps the compiler from hoisting them out of the loop again.
+typedef const WfArgs __attribute__((address_space(4)))* WfArgsKernarg;
+template <class T> __device__ __forceinline__ const T __attribute__((address_space(1)))* wf_glob(const T* p)
+{
+    return (const T __attribute__((address_space(1)))*)p;
+}
+template <class T> __device__ __forceinline__ T __attribute__((address_space(1)))* wf_glob_mut(T* p)
+{
+    return (T __attribute__((address_space(1)))*)p;
+}
+struct WfRaySourceK {
+    static constexpr bool kWantsPoint = false;
+    WfArgsKernarg ap;
+    long long n_paths;
+    int nl;
+    __device__ __forceinline__ WfArgsKernarg args() const { WfArgsKernarg p = ap; __asm__ volatile("" : "+s"(p)); return p; }
+    __device__ __forceinline__ long long total() const { return n_paths * (nl + 1); }
+    __device__ __forceinline__ void split(long long q, int& l, long long& j) const
+    {
+        l = 0; j = q;
+        while (j >= n_paths) { j -= n_paths; l++; }
+    }
+    __device__ __forceinline__ bool fetch(long long q, Ray& r) const
+    {
+        int l; long long j;
+        split(q, l, j);
+        const WfArgsKernarg A = args();
+        const long long cap = A->cap;
+        const bool bounce = l == nl;
+        const int flag = bounce ? wf_glob(A->out.btype)[j] : wf_glob(A->out.expect)[(long long)l * cap + j];
+        V3 p;
+        if (A->depth == 0) {
+            const auto* ph = wf_glob(A->hits) + (A->first_slot + wf_glob(A->out.id)[j] / A->spp);
+            p = mk(ph->p[0], ph->p[1], ph->p[2]);
+        } else {
+            const auto* g = wf_glob(A->out.p);
+            p = mk(g[j], g[cap + j], g[2 * cap + j]);
+        }
+        const auto* d = wf_glob(bounce ? A->out.bdir : A->rays.d + (long long)l * 3 * cap);
+        r.d = mk(d[j], d[cap + j], d[2 * cap + j]);
+        r.o = (bounce && (flag & MCPT_BT_NO_OFFSET)) ? p : p + r.d * 0.01;
+        return bounce ? flag >= 0 : flag != -2;
+    }
+    __device__ __forceinline__ void store(long long q, bool ok, const Hit& h) const
+    {
+        int l; long long j;
+        split(q, l, j);
+        const WfArgsKernarg A = args();
+        if (l == nl) wf_glob_mut(A->out.hit_leaf)[j] = ok ? h.leaf : -1;
+        else wf_glob_mut(A->out.hit_mat)[(long long)l * A->cap + j] = ok ? (h.mat >= 0 ? h.mat : wf_glob(A->tris)[h.leaf].material) : -1;
+    }
+};
+
 }  // namespace mcpt
