@@ -318,6 +318,7 @@ def run_procs(args):
     scene, scene_dir, build_mode = make_scene(M, args, talk=rank == 0)
     dev = M.Device(scene, local_rank, build=build_mode)
     H, W = dev.height, dev.width
+    hip_rt.set_device(local_rank)                   # (the frame buffer and the stream belong to this rank's GPU)
     frame_buf = hip_rt.DeviceBuffer(H * W * 24)
     stream = hip_rt.Stream()
     flags = M.RENDER_KEEP_STATS

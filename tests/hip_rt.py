@@ -23,12 +23,18 @@ def hip():
         L.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
         L.hipStreamDestroy.argtypes = [C.c_void_p]
         L.hipStreamSynchronize.argtypes = [C.c_void_p]
+        L.hipSetDevice.argtypes = [C.c_int]
         _hip = L
     return _hip
 
 
 def check(rc):
     assert rc == 0, "HIP error %d" % rc
+
+
+def set_device(ordinal):
+    """the calling thread's current device (buffers and streams below are created on it)"""
+    check(hip().hipSetDevice(ordinal))
 
 
 class DeviceBuffer:
