@@ -571,10 +571,13 @@ def main():
         cpu_frame_s = (args.width * args.height * args.spp) / cb["samples_per_s"]
         out["cpu_sec_per_frame_extrapolated"] = cpu_frame_s
         out["gpu_over_cpu_frame_time"] = cpu_frame_s / sec_per_frame
-        out["cpu_baseline"]["note"] = ("kind 'port' = the repo's C restatement of the reference, OpenMP over pixel blocks; it is ~4x faster per core than the "
-                                       "reference binary itself (no per-pixel fork/join, no std::string copies, hardware popcount; SURVEY 6: 0.31 Mrays/s on 8 vCPUs "
-                                       "where the port does 1.2).  It traces the reference's 2.7 rays per sample, the GPU 1.6 (primary ray once per pixel, unused "
+        out["cpu_baseline"]["note"] = ("kind 'port' = the repo's C restatement of the reference in reference-cost mode, OpenMP over pixel blocks on every core of "
+                                       "the socket (value); reference_style = the same code under the reference's own parallel structure, min(SPP, 8) threads over "
+                                       "the samples of one pixel at a time, measured in this run.  Per sample the port is cheaper than the reference binary itself "
+                                       "(no std::string copies, hardware popcount: SURVEY 6 measured the binary at 0.31 Mrays/s on 8 vCPUs, where the port in "
+                                       "reference style does 0.29).  It traces the reference's 2.7 rays per sample, the GPU 1.6 (primary ray once per pixel, unused "
                                        "shadow rays skipped): compare frame times (gpu_over_cpu_frame_time), not Mrays/s")
+        out["gpu_over_reference_style_mrays"] = value / cb["reference_style"]["value"]
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     os.close(real_stdout)
