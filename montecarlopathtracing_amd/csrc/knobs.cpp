@@ -35,7 +35,6 @@ const Row kRows[] = {
     {"MCPT_FINISH_PATHS", "1500000 (pool form) / 500000 (lane form)", "paths left at which the finishing pass takes a chunk over; 0: never"},
     {"MCPT_PRE_TEST_MAX_TRIS", "1048576", "largest scene that gets the fp32 pre-test records of its leaf triangles"},
     {"MCPT_SHORT_KERNEL", "1", "0: the voting engine's deep-stack form (36 entries, 3 waves per SIMD) instead of the 27-entry form at 4"},
-    {"MCPT_SPLIT_FRAME", "by frame size", "0 | 1: render a frame as two halves on two streams so that one half's logic passes run beside the other half's trace launches"},
     {"MCPT_LOGIC_GRID", "resident size", "blocks of the logic kernel's grid"},
     {"MCPT_TRACE_BLOCK_RAYS", "2048", "a block of the trace engines is started per this many rays"},
     {"MCPT_TRACE_MIN_CHUNK", "256", "ray slots per queue claim, lower bound"},
@@ -80,7 +79,6 @@ Knobs read_knobs()
     k.finish_paths = env_ll("MCPT_FINISH_PATHS", -1, 0, 1ll << 40);
     k.pre_test_max_tris = env_ll("MCPT_PRE_TEST_MAX_TRIS", k.pre_test_max_tris, 0, 1ll << 40);
     k.short_kernel = (int)env_ll("MCPT_SHORT_KERNEL", 1, 0, 1);
-    k.split_frame = (int)env_ll("MCPT_SPLIT_FRAME", -1, 0, 1);
     k.logic_grid = (unsigned)env_ll("MCPT_LOGIC_GRID", 0, 1, 1 << 20);
     k.trace_block_rays = env_ll("MCPT_TRACE_BLOCK_RAYS", 2048, 256, 1ll << 30);
     k.trace_min_chunk = (int)env_ll("MCPT_TRACE_MIN_CHUNK", 256, 64, 1 << 24) / 64 * 64;

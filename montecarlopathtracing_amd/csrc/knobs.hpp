@@ -16,7 +16,6 @@ struct Knobs {
     long long finish_paths = -1;        // MCPT_FINISH_PATHS: -1 the engine's default
     long long pre_test_max_tris = 1ll << 20;   // MCPT_PRE_TEST_MAX_TRIS
     int short_kernel = 1;               // MCPT_SHORT_KERNEL
-    int split_frame = -1;               // MCPT_SPLIT_FRAME: -1 by frame size, 0 never, 1 always (two halves of a frame on two streams)
     // ---- launch shapes
     unsigned logic_grid = 0;            // MCPT_LOGIC_GRID (0: resident-size grid)
     long long trace_block_rays = 2048;  // MCPT_TRACE_BLOCK_RAYS

@@ -6,9 +6,11 @@
 // needs, runs it, writes back what changed and files the slot under its next class.
 //
 //   * Slot s = k * 64 + lane is only ever handled by lane `lane` (of any wave): every LDS access of a step is [field][k][lane], i.e.
-//     conflict free, and there is no queue between waves -- per lane two 64-bit LDS words hold the class sets, 32 bits each
-//     (bit k of class c: slot k * 64 + lane waits for a step of class c).  Claim = atomic AND that clears the bit (the caller owns the
-//     slot iff the bit was set in the value returned), filing = atomic OR.  A claimed slot is in no set, so nothing else touches it.
+//     conflict free, and there is no queue between waves -- per lane and class one 32-bit LDS word holds the class's set
+//     (bit k of word [c][lane]: slot k * 64 + lane waits for a step of class c).  Claim = atomic AND that clears the bit (the caller owns
+//     the slot iff the bit was set in the value returned), filing = atomic OR.  A claimed slot is in no set, so nothing else touches it.
+//     (Rounds 3 and 4a packed two classes into a 64-bit word: the vote, the claim and the filing were 64-bit shifts, masks and compares
+//     on every lane -- a quarter of the engine's vector instructions went into choosing what to do.)
 //     No wave ever waits for another one: no barrier after the start, no spinning on data (the only sleep is "nothing claimable now").
 //   * A lane has work in class c if any of its KT slots (not held by another wave) waits for c: with a few slots per class that is
 //     nearly always, which is where the lanes per instruction come from -- so a slot is kept small (120 bytes: fp64 ray, 1/d as
@@ -53,14 +55,13 @@ struct NoPaths { static constexpr bool kPaths = false; };
 #ifndef MCPT_POOL_CLAIMS
 #define MCPT_POOL_CLAIMS 2             /* attempts of a lane to claim a slot in one step */
 #endif
-#ifndef MCPT_POOL_GRAB
-#define MCPT_POOL_GRAB 0           /* 1: a claim takes every slot of the class the word shows and hands back all but one (measured: 85.0 vs 81.7 ms, the hidden slots starve the other waves) */
-#endif
+/* (a claim that takes every slot of the class the word shows and hands back all but one was measured in round 3: 85.0 vs 81.7 ms, the
+   hidden slots starve the other waves) */
 #ifndef MCPT_POOL_PREFETCH
 #define MCPT_POOL_PREFETCH 0
 #endif
 #ifndef MCPT_POOL_CACHE_N
-#define MCPT_POOL_CACHE_N 0         /* nodes of the top of the tree held in LDS */
+#define MCPT_POOL_CACHE_N 52        /* nodes of the top of the tree held in LDS (what is left of the 160 KB beside the ray slots) */
 #endif
 #ifndef MCPT_POOL_STICKY
 #define MCPT_POOL_STICKY 0          /* a lane whose slot stays at a node keeps it for the wave's next node step (no filing, no claim) */
@@ -85,6 +86,12 @@ struct NoPaths { static constexpr bool kPaths = false; };
 #endif
 #ifndef MCPT_POOL_FASTPUSH
 #define MCPT_POOL_FASTPUSH 1        /* 0: a branch per pushed child (A/B runs) */
+#endif
+#ifndef MCPT_POOL_NODE_REPEAT
+#define MCPT_POOL_NODE_REPEAT 1     /* node steps a lane may take in a row without giving its slot back */
+#endif
+#ifndef MCPT_POOL_REPEAT_MIN
+#define MCPT_POOL_REPEAT_MIN 32     /* ... as long as this many lanes of the wave go on */
 #endif
 #ifndef MCPT_PW_INNER
 #define MCPT_PW_INNER 4
@@ -138,10 +145,10 @@ struct PoolLds {
     int best_leaf[KT * 64];
     int spf[KT * 64];                       // stack entries (bits 0-7) | flags | leaf: number of triangles, exact class: survivors (bits 16-23)
     int stack[SCAP * KT * 64];              // [entry][k][lane]
-    unsigned long long mask[3 * 64];        // [3][lane]: class c in bits 32 (c & 1) .. + 31 of word c >> 1 (8 bytes per lane: no bank conflict); word 2: path mode
+    unsigned int cls[5 * 64];               // [class][lane]: bit k = slot k * 64 + lane waits for a step of that class (class 4, path mode: bit k = PATH slot k waits for its next vertex)
     unsigned int busy[64];                  // path mode: bit k = ray slot k of this lane is still walking
     int tbl[NW * 64];                       // refill: rank among the fetched rays -> lane that holds it
-    uint4 nodes[MCPT_POOL_CACHE_N ? MCPT_POOL_CACHE_N * 4 : 1];     // the top of the tree (trace_fast.hpp: NodeCache)
+    uint4 nodes[MCPT_POOL_CACHE_N ? MCPT_POOL_CACHE_N * 5 : 1];     // the top of the tree, 80 bytes apart (64 of node, 16 unused: lanes on eight consecutive nodes read without a bank conflict)
     unsigned int stat[8];                   // path mode: shade calls, shadow rays, bounce rays, shadow rays skipped, deepest vertex (flushed by the kernel)
     unsigned int live;                      // slots that may still carry a ray (path mode: path slots that may still carry a path)
     unsigned int dry;                       // waves whose supply of source slots has run out
@@ -164,7 +171,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 {
     static_assert(KT <= 32, "one 32-bit set per class");
     enum { C_INNER = 0, C_LEAF = 1, C_EXACT = 2, C_FIN = 3, C_SHADE = 4, C_DEAD = 5 };
-    enum { F_FOUND = 256, F_AMBIG = 512, F_RAY = 1024 };
+    enum { F_FOUND = 256, F_AMBIG = 512, F_RAY = 1024, F_OWNFAIL = 2048 /* the leader's own box does not pass the reference's box test */ };
     const DFast& F = S.fast;
     const CwNode* __restrict__ nodes = F.cw;
     const DTri* __restrict__ tris = F.tris;
@@ -172,7 +179,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     const long long total = src.total();
     const long long small = chunk < MCPT_TAIL_CHUNK ? chunk : MCPT_TAIL_CHUNK;
     const long long big_tickets = (total - total / 8) / chunk;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));      // (wave: the same in every lane, and the compiler is told so)
     const int stack_max = spill ? SCAP + MCPT_POOL_SPILL : SCAP;
     const int stack_cap = F.stack_cap < stack_max ? F.stack_cap : stack_max;
     int* __restrict__ my_spill = spill ? spill + (size_t)blockIdx.x * MCPT_POOL_SPILL * (KT * 64) : nullptr;
@@ -188,15 +195,19 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     // every slot starts in the finish class without a ray: the first steps of every wave are refills
     // (path mode: every path slot starts free in the SHADE class -- the first steps are adoptions -- and no ray slot is filed)
     for (int k = wave; k < KT; k += NW) { L.spf[k * 64 + lane] = 0; if constexpr (PP::kPaths) L.q[k * 64 + lane] = 0u; }
-    const NodeCache ncache = {L.nodes, F.cached < MCPT_POOL_CACHE_N ? F.cached : MCPT_POOL_CACHE_N};
-    { const uint4* g = reinterpret_cast<const uint4*>(nodes); for (int i = threadIdx.x; i < ncache.n * 4; i += NW * 64) L.nodes[i] = g[i]; }
+    // The vector memory path is what this engine waits for (a step's gathers are one cache lookup per lane and 16-byte group: doubling
+    // the node step's four showed as +20 % of the kernel, removing an eighth of its vector instructions as -2 %), and more than half of
+    // all node steps are on the top three levels of the tree: those nodes are read from LDS.  Two explicit address spaces and a branch
+    // between them -- one pointer that may be either is a flat load, which goes down BOTH paths.
+    const int n_cached = F.cached < MCPT_POOL_CACHE_N ? F.cached : MCPT_POOL_CACHE_N;
+    { const uint4* g = reinterpret_cast<const uint4*>(nodes); for (int i = threadIdx.x; i < n_cached * 4; i += NW * 64) L.nodes[(i >> 2) * 5 + (i & 3)] = g[i]; }
     // path mode: R ray slots per path (one per light and the bounce ray), NP path slots per lane
     int R = 1, NP = KT;
     if constexpr (PP::kPaths) { R = pp.nl + 1; NP = KT / R; }
     if (wave == 0) {
-        L.mask[lane] = 0ull;
-        L.mask[64 + lane] = PP::kPaths ? 0ull : ((1ull << KT) - 1ull) << 32;        // (C_FIN: upper half of word 1)
-        L.mask[128 + lane] = PP::kPaths ? (1ull << NP) - 1ull : 0ull;               // (C_SHADE: lower half of word 2)
+        L.cls[C_INNER * 64 + lane] = 0u; L.cls[C_LEAF * 64 + lane] = 0u; L.cls[C_EXACT * 64 + lane] = 0u;
+        L.cls[C_FIN * 64 + lane] = PP::kPaths ? 0u : (unsigned int)((1ull << KT) - 1ull);
+        L.cls[C_SHADE * 64 + lane] = PP::kPaths ? (unsigned int)((1ull << NP) - 1ull) : 0u;
         L.busy[lane] = 0u;
     }
     if (threadIdx.x == 0) { L.live = (PP::kPaths ? NP : KT) * 64; L.dry = 0; }
@@ -271,20 +282,22 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     };
 
     for (;;) {
-        const unsigned long long m0 = __hip_atomic_load(&L.mask[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const unsigned long long m1 = __hip_atomic_load(&L.mask[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int n_inner = __popcll(__ballot(keep || (unsigned int)m0 != 0u));
-        const int n_leaf = __popcll(__ballot((m0 >> 32) != 0ull));
-        const int n_exact = __popcll(__ballot((unsigned int)m1 != 0u));
+        const unsigned int m_inner = __hip_atomic_load(&L.cls[C_INNER * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned int m_leaf = __hip_atomic_load(&L.cls[C_LEAF * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned int m_exact = __hip_atomic_load(&L.cls[C_EXACT * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned int m_fin = __hip_atomic_load(&L.cls[C_FIN * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int n_inner = __popcll(__ballot(keep || m_inner != 0u));
+        const int n_leaf = __popcll(__ballot(m_leaf != 0u));
+        const int n_exact = __popcll(__ballot(m_exact != 0u));
         // A wave's claim on source slots is private (a chunk per ticket): once the tickets are gone, a wave without a chunk leaves the
         // finish class to the waves that still have rays to hand out; a slot is retired only when every wave of the block is dry.
         const bool fin_ok = PP::kPaths || !queue_empty || uni((int)__hip_atomic_load(&L.dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == NW;
-        const int n_fin = fin_ok ? __popcll(__ballot((m1 >> 32) != 0ull)) : 0;
-        unsigned long long m2 = 0ull;
+        const int n_fin = fin_ok ? __popcll(__ballot(m_fin != 0u)) : 0;
+        unsigned int m_shade = 0u;
         int n_shade = 0;
         if constexpr (PP::kPaths) {
-            m2 = __hip_atomic_load(&L.mask[128 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            n_shade = __popcll(__ballot(m2 != 0ull));
+            m_shade = __hip_atomic_load(&L.cls[C_SHADE * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            n_shade = __popcll(__ballot(m_shade != 0u));
         }
         if (!(n_inner | n_leaf | n_exact | n_fin | n_shade)) {
             // (no lane keeps a slot here: n_inner counts them)
@@ -314,7 +327,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         c = uni(c);
         // slots kept for a node step that is not the next step after all are filed now
         if (c != C_INNER && __ballot(keep)) {
-            if (keep) __hip_atomic_fetch_or(&L.mask[lane], 1ull << keep_k, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (keep) __hip_atomic_fetch_or(&L.cls[C_INNER * 64 + lane], 1u << keep_k, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
             keep = false;
         }
 
@@ -323,47 +336,25 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         bool have = keep;
         int k = keep_k;
         keep = false;
-        unsigned long long cm = c < 2 ? m0 : (c < 4 ? m1 : m2);
-        unsigned long long* const mword = &L.mask[(c >> 1) * 64 + lane];
-        const int mshift = 32 * (c & 1);
-#if MCPT_POOL_GRAB
-        // Claim: take every slot of the class this lane's word shows NOW (one atomic that clears the class's half of the word), keep one,
-        // hand the others straight back.  A claim made on the mask read a moment ago loses whenever another wave's lane of the same index
-        // went for the same bit in between (with 16 waves: a sixth of the lanes); this one only fails if nothing is there at all.
-        {
-            const bool want = !have && (unsigned int)(cm >> mshift) != 0u;
-            if (want) {
-                const unsigned long long cls = 0xffffffffull << mshift;
-                const unsigned long long old = __hip_atomic_fetch_and(mword, ~cls, MCPT_POOL_CLAIM_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned int got = (unsigned int)(old >> mshift);
-                if (got) {
-                    int kk;
-                    if (wave & 1) { const unsigned int lo = got & (0xffffffffu >> (31 - rot)); kk = 31 - __clz((int)(lo ? lo : got)); }
-                    else { const unsigned int hi = got & (0xffffffffu << rot); kk = __ffs((int)(hi ? hi : got)) - 1; }
-                    const unsigned int rest = got & ~(1u << kk);
-                    if (rest) __hip_atomic_fetch_or(mword, (unsigned long long)rest << mshift, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    have = true; k = kk;
-                }
-            }
-        }
-#else
+        unsigned int cm = c == C_INNER ? m_inner : (c == C_LEAF ? m_leaf : (c == C_EXACT ? m_exact : (c == C_FIN ? m_fin : m_shade)));
+        unsigned int* const cword = &L.cls[c * 64 + lane];
+        // (rot and the wave's parity are scalars: the two masks are too, and the choice between them is a scalar branch)
+        const unsigned int below = 0xffffffffu >> (31 - rot), above = 0xffffffffu << rot;
 #pragma unroll
         for (int attempt = 0; attempt < MCPT_POOL_CLAIMS; attempt++) {
-            const unsigned int mc = (unsigned int)(cm >> mshift);
-            const bool want = !have && mc != 0u;
+            const bool want = !have && cm != 0u;
             if (attempt && !__ballot(want)) break;
             if (want) {
                 int kk;
-                if (wave & 1) { const unsigned int lo = mc & (0xffffffffu >> (31 - rot)); kk = 31 - __clz((int)(lo ? lo : mc)); }
-                else { const unsigned int hi = mc & (0xffffffffu << rot); kk = __ffs((int)(hi ? hi : mc)) - 1; }
-                const unsigned long long bit = 1ull << (mshift + kk);
-                const unsigned long long old = __hip_atomic_fetch_and(mword, ~bit, MCPT_POOL_CLAIM_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
-                have = (old & bit) != 0ull;
+                if (wave & 1) { const unsigned int lo = cm & below; kk = 31 - __clz((int)(lo ? lo : cm)); }
+                else { const unsigned int hi = cm & above; kk = __ffs((int)(hi ? hi : cm)) - 1; }
+                const unsigned int bit = 1u << kk;
+                const unsigned int old = __hip_atomic_fetch_and(cword, ~bit, MCPT_POOL_CLAIM_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+                have = (old & bit) != 0u;
                 k = kk;
                 cm = old & ~bit;
             }
         }
-#endif
         rot = rot + 1 == KT ? 0 : rot + 1;
         const unsigned long long hv = __ballot(have);
 #ifdef MCPT_POOL_DEBUG
@@ -381,67 +372,107 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 
         if (c == C_INNER) {
             // ---------------------------------------------------------------- one step on a compressed node
+            // A lane whose ray steps from a node onto another node may take that step at once (MCPT_POOL_NODE_REPEAT > 1), as long as
+            // at least MCPT_POOL_REPEAT_MIN lanes of the wave do: no filing, vote, claim and reload of the ray in between.
             bool refused = false;
+            bool go = have;
+            int cur = 0, spf = 0;
+            RayF rf = {};
+            float limit = 0.0f;
             if (have) {
-                const int cur = L.cur[idx];
-                const int spf = L.spf[idx];
+                cur = L.cur[idx];
+                spf = L.spf[idx];
                 const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolRcp a4 = L.rcp[idx];
-                const float limit = a4.limit;
-                int sp = spf & 255;
-                if (sp > stack_cap - 3) {        // three pushes must fit: the ray goes to the one-lane walk
-                    L.spf[idx] = spf | F_AMBIG; nc = C_FIN; refused = true;
-                } else {
-                    RayF rf;
-                    rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
-                    rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
-                    rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
-#if MCPT_POOL_CACHE_N
-                    const CwHits h = cw_step(nodes, cur, ncache, rf, limit);
-#else
-                    const CwHits h = cw_step(nodes + cur, rf, limit);        // (a global load: a pointer that may be LDS or memory is a flat one)
-#endif
-                    junk += pf; pf = 0;
-#if MCPT_POOL_FASTPUSH
-                    // The children come back sorted with the culled ones last: n hits, the n - 1 farther ones go on the stack, farthest
-                    // first.  When every lane's pushes stay in the LDS part of its stack (nine steps in ten) they are three predicated
-                    // stores at computed positions -- no branch per push, none between LDS and the spill area.
-                    const int n_hit = (h.ref[0] != MCPT_FAST_EMPTY) + (h.ref[1] != MCPT_FAST_EMPTY) + (h.ref[2] != MCPT_FAST_EMPTY) + (h.ref[3] != MCPT_FAST_EMPTY);
-                    if (!__ballot(sp + n_hit - 1 > SCAP)) {
-                        int* const col = &L.stack[k * 64 + lane];
-                        if (n_hit >= 4) col[sp * (KT * 64)] = h.ref[3];
-                        if (n_hit >= 3) col[(sp + n_hit - 3) * (KT * 64)] = h.ref[2];
-                        if (n_hit >= 2) col[(sp + n_hit - 2) * (KT * 64)] = h.ref[1];
-                        sp += n_hit > 1 ? n_hit - 1 : 0;
+                limit = a4.limit;
+                rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
+                rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
+                rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
+            }
+#pragma unroll 1
+            for (int rep = 0;; rep++) {
+                bool again = false, refused_now = false;
+                if (go) {
+                    int sp = spf & 255;
+                    if (sp > stack_cap - 3) {        // three pushes must fit: the ray goes to the one-lane walk
+                        L.spf[idx] = spf | F_AMBIG; nc = C_FIN; refused_now = true;
                     } else {
+#if MCPT_POOL_CACHE_N
+                        // (the LDS side first: the memory side's loads go into the same registers and would otherwise be waited for before the
+                        // LDS reads may even be issued)
+                        typedef unsigned int pool_u4 __attribute__((ext_vector_type(4)));
+                        pool_u4 v0 = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
+                        const bool in_lds = cur < n_cached;
+                        if (in_lds) {
+                            typedef const pool_u4 __attribute__((address_space(3)))* lds_words;
+                            const lds_words q = (lds_words)&L.nodes[cur * 5];
+                            v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
+                        }
+                        __asm__ volatile("" ::: "memory");
+                        if (!in_lds) {
+                            typedef const pool_u4 __attribute__((address_space(1)))* mem_words;
+                            const mem_words q = (mem_words)(nodes + cur);
+                            v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
+                        }
+                        const uint4 w0 = make_uint4(v0.x, v0.y, v0.z, v0.w), w1 = make_uint4(v1.x, v1.y, v1.z, v1.w), w2 = make_uint4(v2.x, v2.y, v2.z, v2.w),
+                                    w3 = make_uint4(v3.x, v3.y, v3.z, v3.w);
+                        const CwHits h = cw_step_words(w0, w1, w2, w3, rf, limit);
+#else
+                        const CwHits h = cw_step(nodes + cur, rf, limit);        // (a global load: a pointer that may be LDS or memory is a flat one)
+#endif
+#ifdef MCPT_POOL_EXTRA_LOADS
+                        // (probe: the node's four 16-byte groups requested a second time -- is the vector cache's lookup rate what bounds the step?)
+                        { const volatile unsigned int* vq = reinterpret_cast<const volatile unsigned int*>(nodes + cur); pf += vq[0] + vq[4] + vq[8] + vq[12]; }
+#endif
+                        junk += pf; pf = 0;
+#if MCPT_POOL_FASTPUSH
+                        // The children come back sorted with the culled ones last: n hits, the n - 1 farther ones go on the stack, farthest
+                        // first.  When every lane's pushes stay in the LDS part of its stack (nine steps in ten) they are three predicated
+                        // stores at computed positions -- no branch per push, none between LDS and the spill area.
+                        const int n_hit = (h.ref[0] != MCPT_FAST_EMPTY) + (h.ref[1] != MCPT_FAST_EMPTY) + (h.ref[2] != MCPT_FAST_EMPTY) + (h.ref[3] != MCPT_FAST_EMPTY);
+                        if (!__ballot(sp + n_hit - 1 > SCAP)) {
+                            int* const col = &L.stack[k * 64 + lane];
+                            if (n_hit >= 4) col[sp * (KT * 64)] = h.ref[3];
+                            if (n_hit >= 3) col[(sp + n_hit - 3) * (KT * 64)] = h.ref[2];
+                            if (n_hit >= 2) col[(sp + n_hit - 2) * (KT * 64)] = h.ref[1];
+                            sp += n_hit > 1 ? n_hit - 1 : 0;
+                        } else {
+                            if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
+                            if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
+                            if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
+                        }
+#else
                         if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
                         if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
                         if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
-                    }
-#else
-                    if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
-                    if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
-                    if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
 #endif
-                    int nxt = h.ref[0];
+                        int nxt = h.ref[0];
 #if MCPT_POOL_FASTPUSH
-                    {
-                        const bool pop = nxt == MCPT_FAST_EMPTY && sp > 0;
-                        if (pop) sp--;
-                        if (!__ballot(pop && sp >= SCAP)) { if (pop) { nxt = L.stack[(sp * KT + k) * 64 + lane]; __asm__ volatile("" : "+v"(nxt)); } }      // (an LDS read, not a flat one)
-                        else if (pop) nxt = st_get(sp, k);
-                    }
+                        {
+                            const bool pop = nxt == MCPT_FAST_EMPTY && sp > 0;
+                            if (pop) sp--;
+                            if (!__ballot(pop && sp >= SCAP)) { if (pop) { nxt = L.stack[(sp * KT + k) * 64 + lane]; __asm__ volatile("" : "+v"(nxt)); } }      // (an LDS read, not a flat one)
+                            else if (pop) nxt = st_get(sp, k);
+                        }
 #else
-                    if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = st_get(sp, k); }
+                        if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = st_get(sp, k); }
 #endif
-                    const bool node = nxt >= 0, none = nxt == MCPT_FAST_EMPTY;
-                    const int ref = -1 - nxt;
-                    const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
-                    if (!none) { touch_next(node, first, cnt); L.cur[idx] = first; }
-                    L.spf[idx] = (spf & 0xff00) | sp | ((!node && !none) ? cnt << 16 : 0);
-                    nc = node ? C_INNER : (none ? C_FIN : C_LEAF);
+                        const bool node = nxt >= 0, none = nxt == MCPT_FAST_EMPTY;
+                        const int ref = -1 - nxt;
+                        const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
+                        if (!none) { touch_next(node, first, cnt); L.cur[idx] = first; }
+                        spf = (spf & 0xff00) | sp | ((!node && !none) ? cnt << 16 : 0);
+                        L.spf[idx] = spf;
+                        nc = node ? C_INNER : (none ? C_FIN : C_LEAF);
+                        again = node; cur = first;
+                    }
                 }
+                c_nodes += (unsigned int)__popcll(__ballot(go && !refused_now));
+                refused = refused || refused_now;
+                if (rep + 1 >= MCPT_POOL_NODE_REPEAT) break;
+                if (__popcll(__ballot(again)) < MCPT_POOL_REPEAT_MIN) break;
+                go = again;
             }
-            c_nodes += (unsigned int)(n_have - __popcll(__ballot(refused)));
+            (void)refused;
         } else if (c == C_LEAF) {
             // ---------------------------------------------------------------- the triangles of a leaf through the fp32 pre-test
             if (have) {
@@ -514,12 +545,16 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     const double ta = (p.x - r.o.x) * fast_rcp(r.d.x);
                     if (ta > 0.0) {
                         const double band = best_t * 0x1p-47;
+                        // The reference tests a leaf's own box before its triangle (bvh_intersect): a leader whose own box fails sends the ray
+                        // to the exact walk when it is finished.  The box is tested here, where the triangle is in registers -- in the result
+                        // step it was five more gathers per ray through the vector memory path, which is what this engine waits for.
                         if (!found || ta < best_t - band) {
                             const PoolRcp a4 = L.rcp[idx];
                             const float of[3] = {(float)a0.ox, (float)a0.oy, (float)a1.oz};
                             L.best_t[idx] = ta; L.best_leaf[idx] = ti;
                             L.rcp[idx].limit = __double2float_ru((ta + ta * 0x1p-47) + (double)margin_of(of, a4));
-                            spf |= F_FOUND;
+                            const bool own = own_box_hit(tr, r, mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z)));
+                            spf = (spf & ~F_OWNFAIL) | F_FOUND | (own ? 0 : F_OWNFAIL);
                         } else if (!(ta > best_t + band)) {
                             // (the leader's hit point again: the first two lines of the reference's test on its triangle, same operands, same bits)
                             const DTri* lt = tris + L.best_leaf[idx];
@@ -527,7 +562,11 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                             const double tl = dot(lv1 - r.o, ln) / dot(ln, r.d);
                             const double old_px = (r.o + r.d * tl).x;
                             const double t_new = (p.x - r.o.x) / r.d.x, t_old = (old_px - r.o.x) / r.d.x;
-                            if (t_new < t_old || (t_new == t_old && tr->leaf < lt->leaf)) { L.best_t[idx] = ta; L.best_leaf[idx] = ti; }
+                            if (t_new < t_old || (t_new == t_old && tr->leaf < lt->leaf)) {
+                                L.best_t[idx] = ta; L.best_leaf[idx] = ti;
+                                const bool own = own_box_hit(tr, r, mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z)));
+                                spf = (spf & ~F_OWNFAIL) | (own ? 0 : F_OWNFAIL);
+                            }
                         }
                     }
                 }
@@ -553,9 +592,8 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     bool ambiguous = (spf & F_AMBIG) != 0;
                     int leaf_ref = -1, mat = -1;
                     if (found) {
-                        const V3 rc = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
                         const DTri* tr = tris + L.best_leaf[idx];
-                        if (!own_box_hit(tr, r, rc)) ambiguous = true;
+                        if (spf & F_OWNFAIL) ambiguous = true;              // (tested when the triangle became the leader)
                         leaf_ref = tr->leaf; mat = tr->material;
                     }
                     if (ambiguous) {
@@ -576,7 +614,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     const int pk = (int)(((float)k + 0.5f) * pp.inv_r);
                     const unsigned int pm = ((1u << R) - 1u) << (pk * R);
                     if (((old & ~bit) & pm) == 0u)
-                        __hip_atomic_fetch_or(&L.mask[128 + lane], 1ull << pk, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(&L.cls[C_SHADE * 64 + lane], 1u << pk, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
                     nc = C_DEAD;                                        // the ray slot is idle until its path's next vertex
                 }
             }
@@ -739,8 +777,8 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     const unsigned int nb = nb_inner | nb_fin;
                     // (the busy bits before the filing: a ray's result step, in another wave, clears its bit)
                     if (nb) __hip_atomic_fetch_or(&L.busy[lane], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (nb_inner) __hip_atomic_fetch_or(&L.mask[lane], (unsigned long long)nb_inner, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (nb_fin) __hip_atomic_fetch_or(&L.mask[64 + lane], (unsigned long long)nb_fin << 32, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (nb_inner) __hip_atomic_fetch_or(&L.cls[C_INNER * 64 + lane], nb_inner, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (nb_fin) __hip_atomic_fetch_or(&L.cls[C_FIN * 64 + lane], nb_fin, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
                     // a path without a ray in flight (nothing to trace at its vertex, or adopted without rays) is resolved by the next step;
                     // a free slot that found no path is retired
                     nc = (mode != P_FREE && !nb) ? C_SHADE : C_DEAD;
@@ -771,9 +809,8 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                     bool ambiguous = (spf & F_AMBIG) != 0;
                     Hit h; h.leaf = -1; h.t = 0; h.p = mk(0, 0, 0);
                     if (found) {
-                        const V3 rc = mk(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
                         const DTri* tr = tris + L.best_leaf[idx];
-                        if (!own_box_hit(tr, r, rc)) ambiguous = true;
+                        if (spf & F_OWNFAIL) ambiguous = true;              // (tested when the triangle became the leader)
                         h.leaf = tr->leaf;
                         h.mat = tr->material;
                         // the hit point: the first two lines of intersect(Ray&, Face&, Vertex&) again -- same operands, same bits as when the
@@ -872,7 +909,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
         if (have && c == C_INNER && nc == C_INNER) { keep = true; keep_k = k; nc = C_DEAD; }      // (not filed: it stays with this lane)
 #endif
         if (have && nc != C_DEAD)
-            __hip_atomic_fetch_or(&L.mask[(nc >> 1) * 64 + lane], 1ull << (32 * (nc & 1) + k), MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&L.cls[nc * 64 + lane], 1u << k, MCPT_POOL_FILE_ORDER, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #undef MCPT_TOUCH
     junk += pf;
