@@ -61,7 +61,8 @@ struct NoPaths { static constexpr bool kPaths = false; };
 #define MCPT_POOL_PREFETCH 0
 #endif
 #ifndef MCPT_POOL_CACHE_N
-#define MCPT_POOL_CACHE_N 52        /* nodes of the top of the tree held in LDS (what is left of the 160 KB beside the ray slots) */
+#define MCPT_POOL_CACHE_N 0         /* nodes of the top of the tree held in LDS; 52 is what the 160 KB leave beside the ray slots -- measured: 7.11 ms per trace
+                                       launch with them, 7.07 without (round 4: the kernel is bound by vector instruction issue, not by its gathers) */
 #endif
 #ifndef MCPT_POOL_STICKY
 #define MCPT_POOL_STICKY 0          /* a lane whose slot stays at a node keeps it for the wave's next node step (no filing, no claim) */
@@ -195,10 +196,8 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
     // every slot starts in the finish class without a ray: the first steps of every wave are refills
     // (path mode: every path slot starts free in the SHADE class -- the first steps are adoptions -- and no ray slot is filed)
     for (int k = wave; k < KT; k += NW) { L.spf[k * 64 + lane] = 0; if constexpr (PP::kPaths) L.q[k * 64 + lane] = 0u; }
-    // The vector memory path is what this engine waits for (a step's gathers are one cache lookup per lane and 16-byte group: doubling
-    // the node step's four showed as +20 % of the kernel, removing an eighth of its vector instructions as -2 %), and more than half of
-    // all node steps are on the top three levels of the tree: those nodes are read from LDS.  Two explicit address spaces and a branch
-    // between them -- one pointer that may be either is a flat load, which goes down BOTH paths.
+    // More than half of all node steps are on the top three levels of the tree: MCPT_POOL_CACHE_N > 0 reads those nodes from LDS.  Two
+    // explicit address spaces and a branch between them -- one pointer that may be either is a flat load, which goes down BOTH paths.
     const int n_cached = F.cached < MCPT_POOL_CACHE_N ? F.cached : MCPT_POOL_CACHE_N;
     { const uint4* g = reinterpret_cast<const uint4*>(nodes); for (int i = threadIdx.x; i < n_cached * 4; i += NW * 64) L.nodes[(i >> 2) * 5 + (i & 3)] = g[i]; }
     // path mode: R ray slots per path (one per light and the bounce ray), NP path slots per lane
@@ -547,7 +546,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                         const double band = best_t * 0x1p-47;
                         // The reference tests a leaf's own box before its triangle (bvh_intersect): a leader whose own box fails sends the ray
                         // to the exact walk when it is finished.  The box is tested here, where the triangle is in registers -- in the result
-                        // step it was five more gathers per ray through the vector memory path, which is what this engine waits for.
+                        // step it was five more gathers and their address arithmetic per ray (-1 % of the kernel).
                         if (!found || ta < best_t - band) {
                             const PoolRcp a4 = L.rcp[idx];
                             const float of[3] = {(float)a0.ox, (float)a0.oy, (float)a1.oz};

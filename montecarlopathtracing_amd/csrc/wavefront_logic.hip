@@ -31,18 +31,74 @@ namespace mcpt {
 #endif
 
 // ---------------------------------------------------------------------------------------------- logic kernel
+// Shade vertex `depth` of sample `id` at path position j (pathTracing.cpp:147-241; the pieces are in vertex.hpp).
+// What is known goes out at once and the bounce is sampled before the lights (every uniform has its own counter: the order of
+// evaluation is free): L, p and the sample id are stored before anything is computed, the incoming direction dies with
+// bounce_sample -- the later passes' values that are alive at the same time, and with them the registers the compiler had to
+// park in scratch memory (39 at 4 waves per SIMD), are what this order is about.
+template <bool FIRST>
+__device__ __forceinline__ void wf_shade_vertex(const DScene& S, const WfArgs& a, long long j, int id, int leaf, const V3& p, const V3& dir, const V3& T, const V3& L,
+                                                int mat_first, int pix_first, const V3& pn_first, const V3& kd_first, LaneStats& ls)
+{
+    const long long cap = a.cap;
+    const int nl = a.nl;
+    const bool folded = nl == 1;
+    const uint32_t depth = (uint32_t)a.depth;
+    a.out.id[j] = id;
+    if (!FIRST) { stc(a.out.L, cap, j, L); stc(a.out.p, cap, j, p); }       // first pass: L = 0; p is the pixel's primary hit (a.hits)
+    const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
+    V3 pn = pn_first, kd = kd_first;
+    if (!FIRST) vertex_surface(S, leaf, p, m, pn, kd);
+
+    RngKey key;
+    key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
+    if (FIRST) key.pixel = (uint32_t)pix_first;
+    else { const int slot = a.first_slot + id / a.spp; key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); }
+    key.sample = (uint32_t)(id % a.spp);
+
+    {
+        V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
+        const int btype = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
+        if (btype >= 0) { stc(a.out.bdir, cap, j, nd); ls.bounce++; }
+        a.out.btype[j] = btype;
+        if (folded) stc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
+        else { stc(a.out.w, cap, j, wgt); if (!FIRST) stc(a.out.T, cap, j, T); }
+    }
+
+    int sample_mat = -1;
+    for (int l = 0; l < nl; l++) {
+        V3 direction, c;
+        const int expect = light_sample(S, key, depth, l, p, pn, kd, sample_mat, direction, c);
+        if (expect != -2) {
+            stc(a.out.c + (long long)l * 3 * cap, cap, j, folded ? mk(T.x * c.x, T.y * c.y, T.z * c.z) : c);
+            stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);       // origin p + direction * 0.01: WfRaySource
+            ls.shadow++;
+        } else ls.skipped++;
+        a.out.expect[(long long)l * cap + j] = expect;
+    }
+}
+
+#ifndef MCPT_LOGIC_RING
+#define MCPT_LOGIC_RING 512         /* vertices a block of the later passes holds between resolving and shading (a power of two >= 511) */
+#endif
+
 // One thread per path position of the previous iteration.  FIRST: positions enumerate (hit slot, k).
+//
+// Later passes (FIRST == false).  Of the positions a pass resolves about half go on to a next vertex (Russian roulette at 0.6, rays that
+// leave the scene, emitters), and shading is the longer half of the kernel: shaded where they were resolved, the surviving vertices ran
+// in waves that were half empty (25 of 64 lanes per vector instruction over the whole kernel, round 4's counters).  A block therefore
+// RESOLVES in rounds of 256 positions and parks the surviving vertices in a ring in LDS -- position, leaf, hit point and radiance so far;
+// the words shading needs beside them (sample id, throughput, incoming direction) are read again from the position, which the block had
+// in its hands a moment ago -- and SHADES in rounds of 256 vertices taken off the ring, every wave full, as soon as 256 are there (and
+// what is left at the end).  One barrier per resolve round (the block-wide prefix), one per shade round (ring and output base visible);
+// a block's output positions are one atomic per shade round.  Ring slots are written after the barrier of a resolve round, which every
+// wave reaches only after its reads of the shade round before: no slot is overwritten while it is read.
 template <bool FIRST>
 __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a)
 {
     const long long n_prev = (long long)a.counts_in->n_next * a.count_mul;
     if (a.queue && blockIdx.x == 0 && threadIdx.x == 0) { a.queue->head = 0ull; a.queue->slow_count = 0u; a.queue->redo_all = 0u; }   // for trace(depth)
     if (!FIRST && n_prev <= (long long)a.finish_below) return;         // those paths went to k_wf_finish
-    // (two sets, used in turn: the values of one block iteration are still being read by its slower waves while the faster ones
-    // write the next iteration's -- with one set that took a third barrier per iteration)
-    __shared__ unsigned int wave_tot[2][4];
-    __shared__ unsigned int block_base[2];
-    int turn = 0;
     const long long cap = a.cap;
     const int nl = a.nl;
     // One light (the usual scene): T * c and T * w / P_RR are formed when the vertex is shaded instead of when it is resolved --
@@ -53,172 +109,172 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
     LaneStats ls;
 #ifdef MCPT_TRACE_DIAG
     unsigned long long dg[4] = {0, 0, 0, 0};
+    unsigned long long tl = __builtin_amdgcn_s_memtime();
 #define MCPT_LSTAMP(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); dg[k] += tn - tl; tl = tn; }
 #else
 #define MCPT_LSTAMP(k)
 #endif
-#ifndef MCPT_FIRST_COMPACT
-    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) a.counts->n_next = a.counts_in->pad[2] * (unsigned int)a.spp;   // shaded pixels x samples
-#endif
     const long long n_round = (n_prev + 255) / 256 * 256;
-    for (long long base = (long long)blockIdx.x * 256; base < n_round; base += (long long)gridDim.x * 256) {
-#ifdef MCPT_TRACE_DIAG
-        unsigned long long tl = __builtin_amdgcn_s_memtime();
-#endif
-        const long long i = base + threadIdx.x;
-        bool alive = false;
-        long long first_pos = 0;
-        int id = 0, leaf = -1, in_type = RT_TRANSMISSION, mat_first = 0, pix_first = 0;
-        V3 p = mk(0, 0, 0), dir = mk(0, 0, 0), T = mk(1, 1, 1), L = mk(0, 0, 0), pn_first = mk(0, 0, 0), kd_first = mk(0, 0, 0);
-        if (i < n_prev) {
-            bool have_vertex;
-            if constexpr (FIRST) {
-                const PrimarySurface* ps = a.surf + i / a.spp;          // the same record for all samples of a pixel
-                const int k = (int)(i % a.spp);
-                // Path positions in exact slot order trace measurably slower on a rank's share of a frame, so the pixels are shuffled
-                // within windows of 2^MCPT_SHUFFLE_LOG2 (an odd multiplier modulo a power of two is a bijection) -- close to the order
-                // the block-wise compaction used to leave.  One eighth of the frame, ms per frame by window: none (slot order) 18.8,
-                // 2^7 17.3, 2^10 16.5, 2^12 18.0, 2^14 18.7, 2^16 18.8; the whole frame is within 0.5 % for all of them.
-                unsigned int an = a.alive_base[(i / a.spp) >> 6] + (unsigned int)ps->alive_index;
-                const unsigned int n_alive = a.counts_in->pad[2];
+    if constexpr (FIRST) {
+        // ---- first pass: no resolve and no compaction -- a pixel's samples live or die together, so k_primary_surface has numbered the
+        // shaded pixels and sample k of pixel number n sits at n * spp + k (no ballot, no atomic, no barrier)
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.counts->n_next = a.counts_in->pad[2] * (unsigned int)a.spp;   // shaded pixels x samples
+        for (long long base = (long long)blockIdx.x * 256; base < n_round; base += (long long)gridDim.x * 256) {
+            const long long i = base + threadIdx.x;
+            if (i >= n_prev) continue;
+            const PrimarySurface* ps = a.surf + i / a.spp;          // the same record for all samples of a pixel
+            const int k = (int)(i % a.spp);
+            // Path positions in exact slot order trace measurably slower on a rank's share of a frame, so the pixels are shuffled
+            // within windows of 2^MCPT_SHUFFLE_LOG2 (an odd multiplier modulo a power of two is a bijection) -- close to the order
+            // the block-wise compaction used to leave.  One eighth of the frame, ms per frame by window: none (slot order) 18.8,
+            // 2^7 17.3, 2^10 16.5, 2^12 18.0, 2^14 18.7, 2^16 18.8; the whole frame is within 0.5 % for all of them.
+            unsigned int an = a.alive_base[(i / a.spp) >> 6] + (unsigned int)ps->alive_index;
+            const unsigned int n_alive = a.counts_in->pad[2];
 #ifndef MCPT_SHUFFLE_LOG2
 #define MCPT_SHUFFLE_LOG2 10
 #endif
-                constexpr unsigned int kWin = (1u << MCPT_SHUFFLE_LOG2) - 1u;
-                if ((an | kWin) < n_alive) an = (an & ~kWin) | ((an & kWin) * 40503u & kWin);      // (not in the last, partial window)
-                first_pos = (long long)an * a.spp + k;
-                id = (ps->slot - a.first_slot) * a.spp + k;
-                leaf = ps->leaf; mat_first = ps->material; pix_first = ps->pixel;
-                p = ld3(ps->p); dir = ld3(ps->dir); pn_first = ld3(ps->pn); kd_first = ld3(ps->kd);
-                have_vertex = true;
-                ls.samples = 1;
-            } else {
-                // ---- resolve vertex depth-1 (pathTracing.cpp:213-231, 244-261)
-                // Every word of the path is requested before any is looked at (what a dead path or an unused shadow slot
-                // holds is stale but harmless): one memory latency per pass instead of a chain of three.
-                id = a.in.id[i];
-                const int bt = a.in.btype[i];
-                const int hl = a.in.hit_leaf[i];
-                // folded (one light): in.T already is the throughput after the bounce and in.c is T * c (see the stores below)
-                if (depth > 1 || folded) T = ldc(a.in.T, cap, i);
-                if (depth > 1) L = ldc(a.in.L, cap, i);
-                V3 wgt = mk(1, 1, 1);
-                if (!folded) wgt = ldc(a.in.w, cap, i);
-                const V3 bd = ldc(a.in.bdir, cap, i);
-                // the vertex the bounce ray left from: the pixel's primary hit after the first pass, in.p afterwards
-                V3 pv;
-                if (depth == 1) { const PrimaryHit* ph = a.hits + (a.first_slot + id / a.spp); pv = mk(ph->p[0], ph->p[1], ph->p[2]); }
-                else pv = ldc(a.in.p, cap, i);
-                V3 L_dir = mk(0, 0, 0);
-                for (int l = 0; l < nl; l++) {
-                    const int expect = a.in.expect[(long long)l * cap + i];
-                    const int hm = a.in.hit_mat[(long long)l * cap + i];
-                    const V3 c = ldc(a.in.c + (long long)l * 3 * cap, cap, i);
-                    if (expect == -2) continue;
-                    const bool vis = hm == expect;
-                    L_dir.x += vis ? c.x : c.x * 0.0;
-                    L_dir.y += vis ? c.y : c.y * 0.0;
-                    L_dir.z += vis ? c.z : c.z * 0.0;
-                }
-                have_vertex = bt >= 0 && hl >= 0;
-                if (folded) {
-                    L = L + L_dir;
-                } else {
-                    L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
-                    if (have_vertex) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
-                }
-                if (have_vertex) {
-                    // the hit point of the bounce ray, as the reference's test formed it when the trace kernel accepted the triangle
-                    // (sceneManagement.cpp:318-320: t = ((v1 - o) . n) / (n . d), p = o + d t; same operands, same operations)
-                    const V3 ro = (bt & MCPT_BT_NO_OFFSET) ? pv : pv + bd * 0.01;
-                    const DTri* tr = S.tris + hl;
-                    const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
-                    const double t = dot(v1 - ro, n) / dot(n, bd);
-                    leaf = hl; p = ro + bd * t; dir = neg(bd); in_type = bt & 7;
-                }
+            constexpr unsigned int kWin = (1u << MCPT_SHUFFLE_LOG2) - 1u;
+            if ((an | kWin) < n_alive) an = (an & ~kWin) | ((an & kWin) * 40503u & kWin);      // (not in the last, partial window)
+            const long long j = (long long)an * a.spp + k;
+            const int id = (ps->slot - a.first_slot) * a.spp + k;
+            const int leaf = ps->leaf, mat_first = ps->material, pix_first = ps->pixel;
+            const V3 p = ld3(ps->p), dir = ld3(ps->dir), pn_first = ld3(ps->pn), kd_first = ld3(ps->kd);
+            ls.samples = 1;
+            ls.shades++;
+            if (depth > ls.depth) ls.depth = depth;
+            const DMaterial* m = S.materials + mat_first;
+            if (m->light >= 0) {                                             // emitter: pathTracing.cpp:141-144
+                const V3 rad = ld3(S.lights[m->light].radiance);
+                a.rad[(size_t)id * 3] = rad.x; a.rad[(size_t)id * 3 + 1] = rad.y; a.rad[(size_t)id * 3 + 2] = rad.z;
+                MCPT_LSTAMP(0)
+                continue;
             }
-            if (have_vertex) {
-                ls.shades++;
-                if (depth > ls.depth) ls.depth = depth;
-                const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
-                if (m->light >= 0) {                                             // emitter: pathTracing.cpp:141-144
-                    const V3 rad = ld3(S.lights[m->light].radiance);
-                    if (FIRST) L = rad;
-                    else if (in_type != RT_DIFFUSE) L = L + mk(T.x * rad.x, T.y * rad.y, T.z * rad.z);
-                } else alive = true;
-            }
-            if (!alive) { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; }
+            MCPT_LSTAMP(0)
+            wf_shade_vertex<true>(S, a, j, id, leaf, p, dir, mk(1, 1, 1), mk(0, 0, 0), mat_first, pix_first, pn_first, kd_first, ls);
+            MCPT_LSTAMP(2)
         }
-        MCPT_LSTAMP(0)
-        // ---- compaction.  First pass: none -- a pixel's samples live or die together, so k_primary_surface has numbered the shaded
-        // pixels and sample k of pixel number n sits at n * spp + k (no ballot, no atomic, no barrier).  Later passes: wave ballot +
-        // prefix, one atomic per block.
-        long long j;
-#ifndef MCPT_FIRST_COMPACT
-        if constexpr (FIRST) {
-            MCPT_LSTAMP(1)
-            if (!alive) continue;
-            j = first_pos;
-        } else
-#endif
-        {
-        const unsigned long long bal = __ballot(alive);
-        const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
-        turn ^= 1;
-        if (lane == 0) wave_tot[turn][wv] = (unsigned int)__popcll(bal);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int tot = wave_tot[turn][0] + wave_tot[turn][1] + wave_tot[turn][2] + wave_tot[turn][3];
+    } else {
+        constexpr unsigned int kRing = MCPT_LOGIC_RING;
+        static_assert((kRing & (kRing - 1u)) == 0u && kRing >= 512u, "a power of two that holds 255 waiting vertices and a round's 256");
+        // (two sets of wave totals, used in turn: the values of one resolve round are still being read by its slower waves while the
+        // faster ones write the next round's)
+        __shared__ unsigned int wave_tot[2][4];
+        __shared__ unsigned int block_base[2];              // (in turn as well: two shade rounds may follow each other without a resolve round between them)
+        __shared__ int ring_pos[kRing], ring_leaf[kRing];
+        __shared__ double ring_p[3][kRing], ring_L[3][kRing];
+        int turn = 0, bturn = 0;
+        unsigned int head = 0, count = 0;                   // the ring: the same values in every thread of the block
+        long long base = (long long)blockIdx.x * 256;
+        for (;;) {
+            while (count < 256u && base < n_round) {
+                // ---- resolve vertex depth-1 of 256 positions (pathTracing.cpp:213-231, 244-261)
+                const long long i = base + threadIdx.x;
+                base += (long long)gridDim.x * 256;
+                bool alive = false;
+                int leaf = -1;
+                V3 p = mk(0, 0, 0), L = mk(0, 0, 0);
+                if (i < n_prev) {
+                    // Every word of the path is requested before any is looked at (what a dead path or an unused shadow slot
+                    // holds is stale but harmless): one memory latency per pass instead of a chain of three.
+                    const int id = a.in.id[i];
+                    const int bt = a.in.btype[i];
+                    const int hl = a.in.hit_leaf[i];
+                    // folded (one light): in.T already is the throughput after the bounce and in.c is T * c (see the stores of
+                    // wf_shade_vertex) -- the resolve needs T only where a specular chain ends on an emitter
+                    V3 T = mk(1, 1, 1);
+                    if (!folded && depth > 1) T = ldc(a.in.T, cap, i);
+                    if (depth > 1) L = ldc(a.in.L, cap, i);
+                    V3 wgt = mk(1, 1, 1);
+                    if (!folded) wgt = ldc(a.in.w, cap, i);
+                    const V3 bd = ldc(a.in.bdir, cap, i);
+                    // the vertex the bounce ray left from: the pixel's primary hit after the first pass, in.p afterwards
+                    V3 pv;
+                    if (depth == 1) { const PrimaryHit* ph = a.hits + (a.first_slot + id / a.spp); pv = mk(ph->p[0], ph->p[1], ph->p[2]); }
+                    else pv = ldc(a.in.p, cap, i);
+                    V3 L_dir = mk(0, 0, 0);
+                    for (int l = 0; l < nl; l++) {
+                        const int expect = a.in.expect[(long long)l * cap + i];
+                        const int hm = a.in.hit_mat[(long long)l * cap + i];
+                        const V3 c = ldc(a.in.c + (long long)l * 3 * cap, cap, i);
+                        if (expect == -2) continue;
+                        const bool vis = hm == expect;
+                        L_dir.x += vis ? c.x : c.x * 0.0;
+                        L_dir.y += vis ? c.y : c.y * 0.0;
+                        L_dir.z += vis ? c.z : c.z * 0.0;
+                    }
+                    const bool have_vertex = bt >= 0 && hl >= 0;
+                    if (folded) {
+                        L = L + L_dir;
+                    } else {
+                        L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
+                        if (have_vertex) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
+                    }
+                    if (have_vertex) {
+                        // the hit point of the bounce ray, as the reference's test formed it when the trace kernel accepted the triangle
+                        // (sceneManagement.cpp:318-320: t = ((v1 - o) . n) / (n . d), p = o + d t; same operands, same operations)
+                        const V3 ro = (bt & MCPT_BT_NO_OFFSET) ? pv : pv + bd * 0.01;
+                        const DTri* tr = S.tris + hl;
+                        const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
+                        const double t = dot(v1 - ro, n) / dot(n, bd);
+                        leaf = hl; p = ro + bd * t;
+                        ls.shades++;
+                        if (depth > ls.depth) ls.depth = depth;
+                        const DMaterial* m = S.materials + tr->material;
+                        if (m->light >= 0) {                                             // emitter: pathTracing.cpp:141-144
+                            if ((bt & 7) != RT_DIFFUSE) {
+                                if (folded) T = ldc(a.in.T, cap, i);
+                                const V3 rad = ld3(S.lights[m->light].radiance);
+                                L = L + mk(T.x * rad.x, T.y * rad.y, T.z * rad.z);
+                            }
+                        } else alive = true;
+                    }
+                    if (!alive) { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; }
+                }
+                MCPT_LSTAMP(0)
+                // ---- the survivors go on the ring: wave ballot + prefix over the block's four waves
+                const unsigned long long bal = __ballot(alive);
+                const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
+                turn ^= 1;
+                if (lane == 0) wave_tot[turn][wv] = (unsigned int)__popcll(bal);
+                __syncthreads();
+                const unsigned int t0 = wave_tot[turn][0], t1 = wave_tot[turn][1], t2 = wave_tot[turn][2], t3 = wave_tot[turn][3];
+                unsigned int off = before + (wv > 0 ? t0 : 0u) + (wv > 1 ? t1 : 0u) + (wv > 2 ? t2 : 0u);
+                if (alive) {
+                    const unsigned int s = (head + count + off) & (kRing - 1u);
+                    ring_pos[s] = (int)i; ring_leaf[s] = leaf;
+                    ring_p[0][s] = p.x; ring_p[1][s] = p.y; ring_p[2][s] = p.z;
+                    ring_L[0][s] = L.x; ring_L[1][s] = L.y; ring_L[2][s] = L.z;
+                }
+                count += t0 + t1 + t2 + t3;
+                MCPT_LSTAMP(1)
+            }
+            if (count == 0u) break;                          // every position resolved, every vertex shaded
+            // ---- shade a round of vertices off the ring: positions block_base .. + m of the pass's output
+            const unsigned int m_round = count < 256u ? count : 256u;
             // (one atomic per 256 paths on one word: with the word sharded 16 ways this kernel's first pass takes 6.0 instead of 6.5 ms --
             // the counter is not its floor)
-            block_base[turn] = tot ? atomicAdd(&a.counts->n_next, tot) : 0u;
+            bturn ^= 1;
+            if (threadIdx.x == 0) block_base[bturn] = atomicAdd(&a.counts->n_next, m_round);
+            __syncthreads();
+            MCPT_LSTAMP(1)
+            if (threadIdx.x < m_round) {
+                const unsigned int s = (head + threadIdx.x) & (kRing - 1u);
+                const long long i = ring_pos[s];
+                const int leaf = ring_leaf[s];
+                const V3 p = mk(ring_p[0][s], ring_p[1][s], ring_p[2][s]), L = mk(ring_L[0][s], ring_L[1][s], ring_L[2][s]);
+                const long long j = (long long)block_base[bturn] + threadIdx.x;
+                // what the resolve round had in its hands beside them, from the position again
+                const int id = a.in.id[i];
+                V3 T = mk(1, 1, 1);
+                if (depth > 1 || folded) T = ldc(a.in.T, cap, i);
+                if (!folded) { const V3 wgt = ldc(a.in.w, cap, i); T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR); }
+                const V3 dir = neg(ldc(a.in.bdir, cap, i));
+                wf_shade_vertex<false>(S, a, j, id, leaf, p, dir, T, L, 0, 0, mk(0, 0, 0), mk(0, 0, 0), ls);
+            }
+            head = (head + m_round) & (kRing - 1u);
+            count -= m_round;
+            MCPT_LSTAMP(2)
         }
-        __syncthreads();
-        unsigned int off = block_base[turn] + before;
-        for (int q = 0; q < wv; q++) off += wave_tot[turn][q];
-        MCPT_LSTAMP(1)
-        if (!alive) continue;
-        j = off;
-        }
-
-        // ---- shade vertex `depth` at position j (pathTracing.cpp:147-241; the pieces are in vertex.hpp)
-        // What is known goes out at once and the bounce is sampled before the lights (every uniform has its own counter: the order of
-        // evaluation is free): L, p and the sample id are stored before anything is computed, the incoming direction dies with
-        // bounce_sample -- the later passes' values that are alive at the same time, and with them the registers the compiler had to
-        // park in scratch memory (39 at 4 waves per SIMD), are what this order is about.
-        a.out.id[j] = id;
-        if (!FIRST) { stc(a.out.L, cap, j, L); stc(a.out.p, cap, j, p); }       // first pass: L = 0; p is the pixel's primary hit (a.hits)
-        const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
-        V3 pn = pn_first, kd = kd_first;
-        if (!FIRST) vertex_surface(S, leaf, p, m, pn, kd);
-
-        RngKey key;
-        key.k0 = (uint32_t)a.seed; key.k1 = (uint32_t)(a.seed >> 32);
-        if (FIRST) key.pixel = (uint32_t)pix_first;
-        else { const int slot = a.first_slot + id / a.spp; key.pixel = (uint32_t)(a.pixels ? a.pixels[slot] : slot); }
-        key.sample = (uint32_t)(id % a.spp);
-
-        {
-            V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
-            const int btype = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
-            if (btype >= 0) { stc(a.out.bdir, cap, j, nd); ls.bounce++; }
-            a.out.btype[j] = btype;
-            if (folded) stc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
-            else { stc(a.out.w, cap, j, wgt); if (!FIRST) stc(a.out.T, cap, j, T); }
-        }
-
-        int sample_mat = -1;
-        for (int l = 0; l < nl; l++) {
-            V3 direction, c;
-            const int expect = light_sample(S, key, depth, l, p, pn, kd, sample_mat, direction, c);
-            if (expect != -2) {
-                stc(a.out.c + (long long)l * 3 * cap, cap, j, folded ? mk(T.x * c.x, T.y * c.y, T.z * c.z) : c);
-                stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);       // origin p + direction * 0.01: WfRaySource
-                ls.shadow++;
-            } else ls.skipped++;
-            a.out.expect[(long long)l * cap + j] = expect;
-        }
-        MCPT_LSTAMP(2)
     }
 #ifdef MCPT_TRACE_DIAG
     if ((threadIdx.x & 63) == 0 && a.ctr) { for (int k = 0; k < 3; k++) atomicAdd(&a.ctr->pad[16 + k], dg[k]); atomicAdd(&a.ctr->pad[19], 1ull); }
