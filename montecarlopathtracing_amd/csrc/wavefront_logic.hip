@@ -78,8 +78,8 @@ __device__ __forceinline__ void wf_shade_vertex(const DScene& S, const WfArgs& a
     }
 }
 
-#ifndef MCPT_LOGIC_RING
-#define MCPT_LOGIC_RING 512         /* vertices a block of the later passes holds between resolving and shading (a power of two >= 511) */
+#ifndef MCPT_LOGIC_PER
+#define MCPT_LOGIC_PER 2            /* positions a thread of the later passes resolves per round (their words are requested together) */
 #endif
 
 // One thread per path position of the previous iteration.  FIRST: positions enumerate (hit slot, k).
@@ -87,12 +87,14 @@ __device__ __forceinline__ void wf_shade_vertex(const DScene& S, const WfArgs& a
 // Later passes (FIRST == false).  Of the positions a pass resolves about half go on to a next vertex (Russian roulette at 0.6, rays that
 // leave the scene, emitters), and shading is the longer half of the kernel: shaded where they were resolved, the surviving vertices ran
 // in waves that were half empty (25 of 64 lanes per vector instruction over the whole kernel, round 4's counters).  A block therefore
-// RESOLVES in rounds of 256 positions and parks the surviving vertices in a ring in LDS -- position, leaf, hit point and radiance so far;
-// the words shading needs beside them (sample id, throughput, incoming direction) are read again from the position, which the block had
-// in its hands a moment ago -- and SHADES in rounds of 256 vertices taken off the ring, every wave full, as soon as 256 are there (and
-// what is left at the end).  One barrier per resolve round (the block-wide prefix), one per shade round (ring and output base visible);
-// a block's output positions are one atomic per shade round.  Ring slots are written after the barrier of a resolve round, which every
-// wave reaches only after its reads of the shade round before: no slot is overwritten while it is read.
+// RESOLVES in rounds of 256 x MCPT_LOGIC_PER positions -- visibility of the shadow rays into the radiance so far, does the bounce ray
+// lead to a surface that is not an emitter -- and parks the survivors in a ring in LDS: position, leaf, radiance (32 bytes).  It SHADES
+// in rounds of 256 vertices taken off the ring, every wave full, as soon as 256 are there (and what is left at the end): the words the
+// next vertex is made of (sample id, throughput, the bounce ray it was reached by) are read from the position then -- for the
+// survivors only, which is a fifth less to read than when every position brought them along.  One barrier per resolve round (the
+// block-wide prefix), one per shade round (ring and output base visible); a block's output positions are one atomic per shade round.
+// Ring slots are written after the barrier of a resolve round, which every wave reaches only after its reads of the shade round
+// before: no slot is overwritten while it is read.
 template <bool FIRST>
 __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOGIC_WAVES) k_wf_logic(DScene S, WfArgs a)
 {
@@ -154,98 +156,98 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
             MCPT_LSTAMP(2)
         }
     } else {
-        constexpr unsigned int kRing = MCPT_LOGIC_RING;
-        static_assert((kRing & (kRing - 1u)) == 0u && kRing >= 512u, "a power of two that holds 255 waiting vertices and a round's 256");
+        constexpr int kPer = MCPT_LOGIC_PER;
+        constexpr unsigned int kRing = 512u * kPer;          // holds the 255 vertices that may wait and a round's 256 x kPer
+        static_assert(kPer == 1 || kPer == 2, "ring size: a power of two");
         // (two sets of wave totals, used in turn: the values of one resolve round are still being read by its slower waves while the
-        // faster ones write the next round's)
-        __shared__ unsigned int wave_tot[2][4];
-        __shared__ unsigned int block_base[2];              // (in turn as well: two shade rounds may follow each other without a resolve round between them)
+        // faster ones write the next round's; the output base in turn as well: two shade rounds may follow each other directly)
+        __shared__ unsigned int wave_tot[2][kPer][4];
+        __shared__ unsigned int block_base[2];
         __shared__ int ring_pos[kRing], ring_leaf[kRing];
-        __shared__ double ring_p[3][kRing], ring_L[3][kRing];
+        __shared__ double ring_L[3][kRing];
         int turn = 0, bturn = 0;
         unsigned int head = 0, count = 0;                   // the ring: the same values in every thread of the block
         long long base = (long long)blockIdx.x * 256;
         for (;;) {
             while (count < 256u && base < n_round) {
-                // ---- resolve vertex depth-1 of 256 positions (pathTracing.cpp:213-231, 244-261)
-                const long long i = base + threadIdx.x;
-                base += (long long)gridDim.x * 256;
-                bool alive = false;
-                int leaf = -1;
-                V3 p = mk(0, 0, 0), L = mk(0, 0, 0);
-                if (i < n_prev) {
-                    // Every word of the path is requested before any is looked at (what a dead path or an unused shadow slot
-                    // holds is stale but harmless): one memory latency per pass instead of a chain of three.
-                    const int id = a.in.id[i];
-                    const int bt = a.in.btype[i];
-                    const int hl = a.in.hit_leaf[i];
+                // ---- resolve vertex depth-1 of 256 x kPer positions (pathTracing.cpp:213-231, 244-261)
+                // Every word is requested before any is looked at (what a dead path or an unused shadow slot holds is stale but
+                // harmless): one memory latency per round instead of a chain of three.
+                long long pos[kPer];
+                int id[kPer], bt[kPer], hl[kPer];
+                V3 L[kPer], T[kPer], wgt[kPer], L_dir[kPer];
+                bool alive[kPer];
+#pragma unroll
+                for (int u = 0; u < kPer; u++) {
+                    pos[u] = base + threadIdx.x;
+                    base += (long long)gridDim.x * 256;
+                    const long long i = pos[u] < n_prev ? pos[u] : 0;       // (past the end: position 0's words, not used)
+                    id[u] = a.in.id[i]; bt[u] = a.in.btype[i]; hl[u] = a.in.hit_leaf[i];
                     // folded (one light): in.T already is the throughput after the bounce and in.c is T * c (see the stores of
                     // wf_shade_vertex) -- the resolve needs T only where a specular chain ends on an emitter
-                    V3 T = mk(1, 1, 1);
-                    if (!folded && depth > 1) T = ldc(a.in.T, cap, i);
-                    if (depth > 1) L = ldc(a.in.L, cap, i);
-                    V3 wgt = mk(1, 1, 1);
-                    if (!folded) wgt = ldc(a.in.w, cap, i);
-                    const V3 bd = ldc(a.in.bdir, cap, i);
-                    // the vertex the bounce ray left from: the pixel's primary hit after the first pass, in.p afterwards
-                    V3 pv;
-                    if (depth == 1) { const PrimaryHit* ph = a.hits + (a.first_slot + id / a.spp); pv = mk(ph->p[0], ph->p[1], ph->p[2]); }
-                    else pv = ldc(a.in.p, cap, i);
-                    V3 L_dir = mk(0, 0, 0);
+                    T[u] = mk(1, 1, 1); L[u] = mk(0, 0, 0); wgt[u] = mk(1, 1, 1); L_dir[u] = mk(0, 0, 0);
+                    if (!folded && depth > 1) T[u] = ldc(a.in.T, cap, i);
+                    if (depth > 1) L[u] = ldc(a.in.L, cap, i);
+                    if (!folded) wgt[u] = ldc(a.in.w, cap, i);
                     for (int l = 0; l < nl; l++) {
                         const int expect = a.in.expect[(long long)l * cap + i];
                         const int hm = a.in.hit_mat[(long long)l * cap + i];
                         const V3 c = ldc(a.in.c + (long long)l * 3 * cap, cap, i);
                         if (expect == -2) continue;
                         const bool vis = hm == expect;
-                        L_dir.x += vis ? c.x : c.x * 0.0;
-                        L_dir.y += vis ? c.y : c.y * 0.0;
-                        L_dir.z += vis ? c.z : c.z * 0.0;
+                        L_dir[u].x += vis ? c.x : c.x * 0.0;
+                        L_dir[u].y += vis ? c.y : c.y * 0.0;
+                        L_dir[u].z += vis ? c.z : c.z * 0.0;
                     }
-                    const bool have_vertex = bt >= 0 && hl >= 0;
-                    if (folded) {
-                        L = L + L_dir;
-                    } else {
-                        L = L + mk(T.x * L_dir.x, T.y * L_dir.y, T.z * L_dir.z);
-                        if (have_vertex) T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR);
+                }
+#pragma unroll
+                for (int u = 0; u < kPer; u++) {
+                    alive[u] = false;
+                    if (pos[u] < n_prev) {
+                        const bool have_vertex = bt[u] >= 0 && hl[u] >= 0;
+                        if (folded) L[u] = L[u] + L_dir[u];
+                        else {
+                            L[u] = L[u] + mk(T[u].x * L_dir[u].x, T[u].y * L_dir[u].y, T[u].z * L_dir[u].z);
+                            if (have_vertex) T[u] = mk(T[u].x * wgt[u].x * MCPT_INV_P_RR, T[u].y * wgt[u].y * MCPT_INV_P_RR, T[u].z * wgt[u].z * MCPT_INV_P_RR);
+                        }
+                        if (have_vertex) {
+                            ls.shades++;
+                            if (depth > ls.depth) ls.depth = depth;
+                            const DMaterial* m = S.materials + S.tris[hl[u]].material;
+                            if (m->light >= 0) {                                         // emitter: pathTracing.cpp:141-144
+                                if ((bt[u] & 7) != RT_DIFFUSE) {
+                                    if (folded) T[u] = ldc(a.in.T, cap, pos[u]);
+                                    const V3 rad = ld3(S.lights[m->light].radiance);
+                                    L[u] = L[u] + mk(T[u].x * rad.x, T[u].y * rad.y, T[u].z * rad.z);
+                                }
+                            } else alive[u] = true;
+                        }
+                        if (!alive[u]) { a.rad[(size_t)id[u] * 3] = L[u].x; a.rad[(size_t)id[u] * 3 + 1] = L[u].y; a.rad[(size_t)id[u] * 3 + 2] = L[u].z; }
                     }
-                    if (have_vertex) {
-                        // the hit point of the bounce ray, as the reference's test formed it when the trace kernel accepted the triangle
-                        // (sceneManagement.cpp:318-320: t = ((v1 - o) . n) / (n . d), p = o + d t; same operands, same operations)
-                        const V3 ro = (bt & MCPT_BT_NO_OFFSET) ? pv : pv + bd * 0.01;
-                        const DTri* tr = S.tris + hl;
-                        const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
-                        const double t = dot(v1 - ro, n) / dot(n, bd);
-                        leaf = hl; p = ro + bd * t;
-                        ls.shades++;
-                        if (depth > ls.depth) ls.depth = depth;
-                        const DMaterial* m = S.materials + tr->material;
-                        if (m->light >= 0) {                                             // emitter: pathTracing.cpp:141-144
-                            if ((bt & 7) != RT_DIFFUSE) {
-                                if (folded) T = ldc(a.in.T, cap, i);
-                                const V3 rad = ld3(S.lights[m->light].radiance);
-                                L = L + mk(T.x * rad.x, T.y * rad.y, T.z * rad.z);
-                            }
-                        } else alive = true;
-                    }
-                    if (!alive) { a.rad[(size_t)id * 3] = L.x; a.rad[(size_t)id * 3 + 1] = L.y; a.rad[(size_t)id * 3 + 2] = L.z; }
                 }
                 MCPT_LSTAMP(0)
-                // ---- the survivors go on the ring: wave ballot + prefix over the block's four waves
-                const unsigned long long bal = __ballot(alive);
-                const unsigned int before = __popcll(bal & ((1ull << lane) - 1ull));
+                // ---- the survivors go on the ring: wave ballots + prefix over the block's four waves, sub-round by sub-round
+                unsigned int before[kPer];
                 turn ^= 1;
-                if (lane == 0) wave_tot[turn][wv] = (unsigned int)__popcll(bal);
-                __syncthreads();
-                const unsigned int t0 = wave_tot[turn][0], t1 = wave_tot[turn][1], t2 = wave_tot[turn][2], t3 = wave_tot[turn][3];
-                unsigned int off = before + (wv > 0 ? t0 : 0u) + (wv > 1 ? t1 : 0u) + (wv > 2 ? t2 : 0u);
-                if (alive) {
-                    const unsigned int s = (head + count + off) & (kRing - 1u);
-                    ring_pos[s] = (int)i; ring_leaf[s] = leaf;
-                    ring_p[0][s] = p.x; ring_p[1][s] = p.y; ring_p[2][s] = p.z;
-                    ring_L[0][s] = L.x; ring_L[1][s] = L.y; ring_L[2][s] = L.z;
+#pragma unroll
+                for (int u = 0; u < kPer; u++) {
+                    const unsigned long long bal = __ballot(alive[u]);
+                    before[u] = __popcll(bal & ((1ull << lane) - 1ull));
+                    if (lane == 0) wave_tot[turn][u][wv] = (unsigned int)__popcll(bal);
                 }
-                count += t0 + t1 + t2 + t3;
+                __syncthreads();
+                unsigned int at = head + count;
+#pragma unroll
+                for (int u = 0; u < kPer; u++) {
+                    const unsigned int t0 = wave_tot[turn][u][0], t1 = wave_tot[turn][u][1], t2 = wave_tot[turn][u][2], t3 = wave_tot[turn][u][3];
+                    if (alive[u]) {
+                        const unsigned int s = (at + before[u] + (wv > 0 ? t0 : 0u) + (wv > 1 ? t1 : 0u) + (wv > 2 ? t2 : 0u)) & (kRing - 1u);
+                        ring_pos[s] = (int)pos[u]; ring_leaf[s] = hl[u];
+                        ring_L[0][s] = L[u].x; ring_L[1][s] = L[u].y; ring_L[2][s] = L[u].z;
+                    }
+                    at += t0 + t1 + t2 + t3;
+                }
+                count = at - head;
                 MCPT_LSTAMP(1)
             }
             if (count == 0u) break;                          // every position resolved, every vertex shaded
@@ -261,15 +263,27 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
                 const unsigned int s = (head + threadIdx.x) & (kRing - 1u);
                 const long long i = ring_pos[s];
                 const int leaf = ring_leaf[s];
-                const V3 p = mk(ring_p[0][s], ring_p[1][s], ring_p[2][s]), L = mk(ring_L[0][s], ring_L[1][s], ring_L[2][s]);
+                const V3 L = mk(ring_L[0][s], ring_L[1][s], ring_L[2][s]);
                 const long long j = (long long)block_base[bturn] + threadIdx.x;
-                // what the resolve round had in its hands beside them, from the position again
+                // the sample, its throughput and the bounce ray that reached this vertex, from the position
                 const int id = a.in.id[i];
+                const int bt = a.in.btype[i];
                 V3 T = mk(1, 1, 1);
                 if (depth > 1 || folded) T = ldc(a.in.T, cap, i);
                 if (!folded) { const V3 wgt = ldc(a.in.w, cap, i); T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR); }
-                const V3 dir = neg(ldc(a.in.bdir, cap, i));
-                wf_shade_vertex<false>(S, a, j, id, leaf, p, dir, T, L, 0, 0, mk(0, 0, 0), mk(0, 0, 0), ls);
+                const V3 bd = ldc(a.in.bdir, cap, i);
+                // the vertex the bounce ray left from: the pixel's primary hit after the first pass, in.p afterwards
+                V3 pv;
+                if (depth == 1) { const PrimaryHit* ph = a.hits + (a.first_slot + id / a.spp); pv = mk(ph->p[0], ph->p[1], ph->p[2]); }
+                else pv = ldc(a.in.p, cap, i);
+                // the hit point of the bounce ray, as the reference's test formed it when the trace kernel accepted the triangle
+                // (sceneManagement.cpp:318-320: t = ((v1 - o) . n) / (n . d), p = o + d t; same operands, same operations)
+                const V3 ro = (bt & MCPT_BT_NO_OFFSET) ? pv : pv + bd * 0.01;
+                const DTri* tr = S.tris + leaf;
+                const V3 v1 = ld3(tr->v1), n = ld3(tr->n);
+                const double t = dot(v1 - ro, n) / dot(n, bd);
+                const V3 p = ro + bd * t;
+                wf_shade_vertex<false>(S, a, j, id, leaf, p, neg(bd), T, L, 0, 0, mk(0, 0, 0), mk(0, 0, 0), ls);
             }
             head = (head + m_round) & (kRing - 1u);
             count -= m_round;
