@@ -88,12 +88,6 @@ struct NoPaths { static constexpr bool kPaths = false; };
 #ifndef MCPT_POOL_FASTPUSH
 #define MCPT_POOL_FASTPUSH 1        /* 0: a branch per pushed child (A/B runs) */
 #endif
-#ifndef MCPT_POOL_NODE_REPEAT
-#define MCPT_POOL_NODE_REPEAT 1     /* node steps a lane may take in a row without giving its slot back */
-#endif
-#ifndef MCPT_POOL_REPEAT_MIN
-#define MCPT_POOL_REPEAT_MIN 32     /* ... as long as this many lanes of the wave go on */
-#endif
 #ifndef MCPT_PW_INNER
 #define MCPT_PW_INNER 4
 #endif
@@ -223,7 +217,10 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 #endif
     long long next = 0, range_end = 0;          // unclaimed part of the wave's chunk of source slots
     bool queue_empty = false;
-    int rot = wave % KT;                        // where a lane starts to look for a set bit: rotates, so no slot waits forever
+    int rot = wave % KT;                        // where a lane starts to look for a set bit: rotates, so no slot waits forever --
+    // every pair of waves with a stride of its own (11, 13, 17, 19: odd, and coprime to the 20 slots), so that two waves after the same
+    // class do not keep looking at the same slot first (-0.5 % of the kernel against a common stride of 1)
+    const int rot_stride = (int)((0x13110d0bu >> (8 * ((wave >> 1) & 3))) & 255u) % KT | 1;
     bool keep = false;                          // MCPT_POOL_STICKY: this lane still owns slot keep_k, which waits for a node step
     int keep_k = 0;
 #if MCPT_POOL_PREF
@@ -354,7 +351,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                 cm = old & ~bit;
             }
         }
-        rot = rot + 1 == KT ? 0 : rot + 1;
+        { rot += rot_stride; if (rot >= KT) rot -= KT; }
         const unsigned long long hv = __ballot(have);
 #ifdef MCPT_POOL_DEBUG
         if (!hv) d_miss++;
@@ -371,29 +368,22 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 
         if (c == C_INNER) {
             // ---------------------------------------------------------------- one step on a compressed node
-            // A lane whose ray steps from a node onto another node may take that step at once (MCPT_POOL_NODE_REPEAT > 1), as long as
-            // at least MCPT_POOL_REPEAT_MIN lanes of the wave do: no filing, vote, claim and reload of the ray in between.
+            // (a lane that stays on nodes taking its next node step at once -- no filing, vote, claim and reload in between, at the lanes
+            // that happen to go on -- was measured in round 4: no difference at two, three or four steps in a row)
             bool refused = false;
-            bool go = have;
-            int cur = 0, spf = 0;
-            RayF rf = {};
-            float limit = 0.0f;
-            if (have) {
-                cur = L.cur[idx];
-                spf = L.spf[idx];
-                const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolRcp a4 = L.rcp[idx];
-                limit = a4.limit;
-                rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
-                rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
-                rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
-            }
-#pragma unroll 1
-            for (int rep = 0;; rep++) {
-                bool again = false, refused_now = false;
-                if (go) {
+            {
+                if (have) {
+                    int cur = L.cur[idx];
+                    int spf = L.spf[idx];
+                    const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolRcp a4 = L.rcp[idx];
+                    const float limit = a4.limit;
+                    RayF rf;
+                    rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
+                    rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
+                    rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
                     int sp = spf & 255;
                     if (sp > stack_cap - 3) {        // three pushes must fit: the ray goes to the one-lane walk
-                        L.spf[idx] = spf | F_AMBIG; nc = C_FIN; refused_now = true;
+                        L.spf[idx] = spf | F_AMBIG; nc = C_FIN; refused = true;
                     } else {
 #if MCPT_POOL_CACHE_N
                         // (the LDS side first: the memory side's loads go into the same registers and would otherwise be waited for before the
@@ -418,10 +408,7 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
 #else
                         const CwHits h = cw_step(nodes + cur, rf, limit);        // (a global load: a pointer that may be LDS or memory is a flat one)
 #endif
-#ifdef MCPT_POOL_EXTRA_LOADS
-                        // (probe: the node's four 16-byte groups requested a second time -- is the vector cache's lookup rate what bounds the step?)
-                        { const volatile unsigned int* vq = reinterpret_cast<const volatile unsigned int*>(nodes + cur); pf += vq[0] + vq[4] + vq[8] + vq[12]; }
-#endif
+
                         junk += pf; pf = 0;
 #if MCPT_POOL_FASTPUSH
                         // The children come back sorted with the culled ones last: n hits, the n - 1 farther ones go on the stack, farthest
@@ -462,16 +449,11 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
                         spf = (spf & 0xff00) | sp | ((!node && !none) ? cnt << 16 : 0);
                         L.spf[idx] = spf;
                         nc = node ? C_INNER : (none ? C_FIN : C_LEAF);
-                        again = node; cur = first;
+                        (void)cur;
                     }
                 }
-                c_nodes += (unsigned int)__popcll(__ballot(go && !refused_now));
-                refused = refused || refused_now;
-                if (rep + 1 >= MCPT_POOL_NODE_REPEAT) break;
-                if (__popcll(__ballot(again)) < MCPT_POOL_REPEAT_MIN) break;
-                go = again;
             }
-            (void)refused;
+            c_nodes += (unsigned int)(n_have - __popcll(__ballot(refused)));
         } else if (c == C_LEAF) {
             // ---------------------------------------------------------------- the triangles of a leaf through the fp32 pre-test
             if (have) {
