@@ -1191,7 +1191,7 @@ static int render_wavefront(mcpt_device* d, mcpt_device::FrameSlot& f, const mcp
     WfState A, B;
     if (!wf_carve(f.wf_ws, f.wf_ws_bytes, cap, nl, A, B, a.rays)) return fail(MCPT_ERR_NOMEM, "wavefront workspace too small");
     a.cap = cap; a.nl = nl; a.spp = spp; a.seed = p->seed; a.pixels = d->pixels; a.hit_slots = f.hit_slots; a.surf = f.surf; a.alive_base = f.alive_base; a.hits = f.hits;
-    a.dirs = d->dirs; a.rad = f.rad; a.counts = f.wf_counts; a.ctr = f.ctr; a.tris = d->tris; a.queue = fast ? f.queue : nullptr;
+    a.dirs = d->dirs; a.rad = f.rad; a.counts = f.wf_counts; a.ctr = f.ctr; a.tris = d->tris; a.materials = d->materials; a.queue = fast ? f.queue : nullptr;
     a.finish_below = fast ? unsigned(std::min<long long>(std::max<long long>(d->finish_threshold, 0), 1ll << 30)) : 0u;
     // Iterations are enqueued without waiting for their counts: every kernel reads its input count from the device slot the
     // previous one wrote.  The host looks at a count only every few iterations (to stop, and to size the next grids).

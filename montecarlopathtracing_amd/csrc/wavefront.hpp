@@ -28,7 +28,7 @@ struct WfState {            // one side of the double buffer; every array has `c
     int32_t* btype;         // [cap] ray_type of the bounce ray (| MCPT_BT_NO_OFFSET: it starts at the vertex itself), -1 = none
     // what trace(d) adds:
     int32_t* hit_mat;       // [nl][cap] material of the shadow ray's closest hit, -1 = miss
-    int32_t* hit_leaf;      // [cap]     bounce ray: leaf or -1.  The hit point is not stored: the next logic pass forms it again from the
+    int32_t* hit_leaf;      // [cap]     bounce ray: leaf (| MCPT_HIT_EMITTER when its material is a light) or -1.  The hit point is not stored: the next logic pass forms it again from the
                             //           ray it rebuilds and the leaf's plane -- the first two lines of the reference's triangle test on the
                             //           same operands, hence the same bits -- which takes 24 bytes per bounce ray off the trace kernel's
                             //           scattered stores and ~45 instructions per finished ray off the instruction-bound kernel
@@ -52,6 +52,12 @@ struct alignas(16) PrimarySurface {
     int32_t alive_index, pad[3];    // rank of the pixel among the shaded (non-emitter) pixels of its group of 64 hit slots, -1 on an emitter:
                                     // the first logic pass puts sample k at path position (alive_base[group] + alive_index) * spp + k -- no compaction
 };
+
+// A bounce ray's answer carries whether the surface it reached is a light: the trace kernels have the triangle's material at hand, and
+// the next logic pass then knows which paths go on from the words of the path alone (no triangle and no material fetched before its
+// block-wide prefix -- two dependent round trips per resolve round).
+#define MCPT_HIT_EMITTER 0x40000000
+#define MCPT_HIT_LEAF_MASK 0x3fffffff
 
 struct TraceQueue {                 // persistent trace kernels; device words, zeroed before each launch
     unsigned long long head;        // next ticket (trace_persistent.hpp maps tickets to ray slots)
@@ -85,6 +91,7 @@ struct WfArgs {
     unsigned int count_mul;     // input paths = counts_in->n_next * count_mul (spp for the first pass, 1 afterwards)
     DCounters* ctr;
     const DTri* tris;           // S.tris (material of a shadow ray's hit)
+    const DMaterial* materials; // S.materials (is the surface a bounce ray reached an emitter: MCPT_HIT_EMITTER)
     // Hand-over to the finishing kernel, decided on the device: when logic(d) leaves at most this many paths, k_wf_finish
     // (launched after every logic pass) runs them to their end and trace(d), logic(d+1), ... find nothing to do.  0 = never.
     unsigned int finish_below;

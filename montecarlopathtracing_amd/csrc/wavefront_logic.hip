@@ -213,9 +213,10 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
                         if (have_vertex) {
                             ls.shades++;
                             if (depth > ls.depth) ls.depth = depth;
-                            const DMaterial* m = S.materials + S.tris[hl[u]].material;
-                            if (m->light >= 0) {                                         // emitter: pathTracing.cpp:141-144
+                            // (is the surface an emitter: the trace kernel said so with the leaf, MCPT_HIT_EMITTER)
+                            if (hl[u] & MCPT_HIT_EMITTER) {                              // emitter: pathTracing.cpp:141-144
                                 if ((bt[u] & 7) != RT_DIFFUSE) {
+                                    const DMaterial* m = S.materials + S.tris[hl[u] & MCPT_HIT_LEAF_MASK].material;
                                     if (folded) T[u] = ldc(a.in.T, cap, pos[u]);
                                     const V3 rad = ld3(S.lights[m->light].radiance);
                                     L[u] = L[u] + mk(T[u].x * rad.x, T[u].y * rad.y, T[u].z * rad.z);
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
                     const unsigned int t0 = wave_tot[turn][u][0], t1 = wave_tot[turn][u][1], t2 = wave_tot[turn][u][2], t3 = wave_tot[turn][u][3];
                     if (alive[u]) {
                         const unsigned int s = (at + before[u] + (wv > 0 ? t0 : 0u) + (wv > 1 ? t1 : 0u) + (wv > 2 ? t2 : 0u)) & (kRing - 1u);
-                        ring_pos[s] = (int)pos[u]; ring_leaf[s] = hl[u];
+                        ring_pos[s] = (int)pos[u]; ring_leaf[s] = hl[u];        // (alive: no flag in it)
                         ring_L[0][s] = L[u].x; ring_L[1][s] = L[u].y; ring_L[2][s] = L[u].z;
                     }
                     at += t0 + t1 + t2 + t3;
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
         }
     }
 #ifdef MCPT_TRACE_DIAG
-    if ((threadIdx.x & 63) == 0 && a.ctr) { for (int k = 0; k < 3; k++) atomicAdd(&a.ctr->pad[16 + k], dg[k]); atomicAdd(&a.ctr->pad[19], 1ull); }
+    if (!FIRST && (threadIdx.x & 63) == 0 && a.ctr) { for (int k = 0; k < 3; k++) atomicAdd(&a.ctr->pad[16 + k], dg[k]); atomicAdd(&a.ctr->pad[19], 1ull); }     // (the later passes' account)
 #endif
     flush_stats(a.ctr, ls);
 }

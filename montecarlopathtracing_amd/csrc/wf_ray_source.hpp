@@ -45,7 +45,9 @@ struct WfRaySource {
         int l; long long j;
         split(q, l, j);
         if (l == a.nl) {
-            a.out.hit_leaf[j] = ok ? h.leaf : -1;
+            int v = -1;
+            if (ok) { const int mat = h.mat >= 0 ? h.mat : a.tris[h.leaf].material; v = h.leaf | (a.materials[mat].light >= 0 ? MCPT_HIT_EMITTER : 0); }
+            a.out.hit_leaf[j] = v;
         } else {
             // (the persistent engine hands the material over with the leaf: one dependent fetch less per shadow ray in its store batch)
             a.out.hit_mat[(long long)l * a.cap + j] = ok ? (h.mat >= 0 ? h.mat : a.tris[h.leaf].material) : -1;
@@ -106,7 +108,11 @@ struct WfRaySourceK {
         int l; long long j;
         split(q, l, j);
         const WfArgsKernarg A = args();
-        if (l == nl) wf_glob_mut(A->out.hit_leaf)[j] = ok ? h.leaf : -1;
+        if (l == nl) {
+            int v = -1;
+            if (ok) { const int mat = h.mat >= 0 ? h.mat : wf_glob(A->tris)[h.leaf].material; v = h.leaf | (wf_glob(A->materials)[mat].light >= 0 ? MCPT_HIT_EMITTER : 0); }
+            wf_glob_mut(A->out.hit_leaf)[j] = v;
+        }
         else wf_glob_mut(A->out.hit_mat)[(long long)l * A->cap + j] = ok ? (h.mat >= 0 ? h.mat : wf_glob(A->tris)[h.leaf].material) : -1;
     }
 };

@@ -333,6 +333,31 @@ def test_wavefront_iterations_against_megakernel_and_oracle(pair, oracle, mcpt, 
         dev.close()
 
 
+def test_logic_ring_many_rounds_in_two_blocks(pair, mcpt, monkeypatch):
+    """The later passes of k_wf_logic resolve in rounds of 512 positions per block, park the vertices that go on in a ring in LDS
+    (1024 slots) and shade them 256 at a time, every wave full (wavefront_logic.hip).  With the logic grid forced down to two blocks
+    (MCPT_LOGIC_GRID=2) a 160x90 SPP-16 frame -- 230 k samples, some 100 k positions in the first later pass -- takes each block
+    through a hundred resolve rounds: the ring wraps dozens of times, resolve rounds that leave fewer than 256 vertices waiting are
+    followed by another, the drain at the end shades a partial round.  One light (folded state) and several (unfolded) through the
+    scene fixture; the hand-over to the finishing pass switched off so that every bounce is a logic pass.  Bit for bit against the
+    megakernel, with the same counts."""
+    name, osc, sc, dev0 = pair
+    monkeypatch.setenv("MCPT_FINISH_PATHS", "0")
+    monkeypatch.setenv("MCPT_LOGIC_GRID", "2")
+    dev = mcpt.Device(sc, 0)
+    try:
+        sa, sb = mcpt.Stats(), mcpt.Stats()
+        a = dev.generateImg(16, seed=11, stats=sa)
+        b = dev.generateImg(16, seed=11, flags=mcpt.RENDER_MEGAKERNEL)
+        assert np.array_equal(_bits(a), _bits(b)), "%d channels differ from the megakernel" % int((_bits(a) != _bits(b)).sum())
+        assert sa.launches >= 5, sa.launches
+        c = dev0.generateImg(16, seed=11, stats=sb)           # (the fixture's device: default grid, finishing pass on)
+        assert np.array_equal(_bits(a), _bits(c))
+        assert (sa.rays_shadow + sa.shadow_skipped, sa.rays_bounce, sa.shade_calls) == (sb.rays_shadow + sb.shadow_skipped, sb.rays_bounce, sb.shade_calls)
+    finally:
+        dev.close()
+
+
 def test_pool_engine_equals_voting_engine(pair, mcpt, monkeypatch):
     """The library picks the closest-hit engine by scene size (mcpt_scene_trace_engine): the pool engine, whose rays live in LDS
     (csrc/trace_pool.hpp: stateless wave steps on slots claimed with LDS atomics), for the primary rays, mcpt_trace_closest and every
