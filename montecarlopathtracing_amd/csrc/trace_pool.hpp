@@ -371,86 +371,83 @@ __device__ __forceinline__ void trace_pool(const DScene& S, const Src& src, Trac
             // (a lane that stays on nodes taking its next node step at once -- no filing, vote, claim and reload in between, at the lanes
             // that happen to go on -- was measured in round 4: no difference at two, three or four steps in a row)
             bool refused = false;
-            {
-                if (have) {
-                    int cur = L.cur[idx];
-                    int spf = L.spf[idx];
-                    const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolRcp a4 = L.rcp[idx];
-                    const float limit = a4.limit;
-                    RayF rf;
-                    rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
-                    rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
-                    rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
-                    int sp = spf & 255;
-                    if (sp > stack_cap - 3) {        // three pushes must fit: the ray goes to the one-lane walk
-                        L.spf[idx] = spf | F_AMBIG; nc = C_FIN; refused = true;
-                    } else {
+            if (have) {
+                const int cur = L.cur[idx];
+                int spf = L.spf[idx];
+                const PoolOxy a0 = pool_ld16(&L.oxy[idx]); const PoolOzDx a1 = pool_ld16(&L.ozdx[idx]); const PoolRcp a4 = L.rcp[idx];
+                const float limit = a4.limit;
+                RayF rf;
+                rf.o[0] = (float)a0.ox; rf.o[1] = (float)a0.oy; rf.o[2] = (float)a1.oz;
+                rf.r[0] = a4.rx; rf.r[1] = a4.ry; rf.r[2] = a4.rz;
+                rf.pad[0] = pad_of(rf.o[0], a4.rx); rf.pad[1] = pad_of(rf.o[1], a4.ry); rf.pad[2] = pad_of(rf.o[2], a4.rz);
+                int sp = spf & 255;
+                if (sp > stack_cap - 3) {        // three pushes must fit: the ray goes to the one-lane walk
+                    L.spf[idx] = spf | F_AMBIG; nc = C_FIN; refused = true;
+                } else {
 #if MCPT_POOL_CACHE_N
-                        // (the LDS side first: the memory side's loads go into the same registers and would otherwise be waited for before the
-                        // LDS reads may even be issued)
-                        typedef unsigned int pool_u4 __attribute__((ext_vector_type(4)));
-                        pool_u4 v0 = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
-                        const bool in_lds = cur < n_cached;
-                        if (in_lds) {
-                            typedef const pool_u4 __attribute__((address_space(3)))* lds_words;
-                            const lds_words q = (lds_words)&L.nodes[cur * 5];
-                            v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
-                        }
-                        __asm__ volatile("" ::: "memory");
-                        if (!in_lds) {
-                            typedef const pool_u4 __attribute__((address_space(1)))* mem_words;
-                            const mem_words q = (mem_words)(nodes + cur);
-                            v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
-                        }
-                        const uint4 w0 = make_uint4(v0.x, v0.y, v0.z, v0.w), w1 = make_uint4(v1.x, v1.y, v1.z, v1.w), w2 = make_uint4(v2.x, v2.y, v2.z, v2.w),
-                                    w3 = make_uint4(v3.x, v3.y, v3.z, v3.w);
-                        const CwHits h = cw_step_words(w0, w1, w2, w3, rf, limit);
+                    // (the LDS side first: the memory side's loads go into the same registers and would otherwise be waited for before the
+                    // LDS reads may even be issued)
+                    typedef unsigned int pool_u4 __attribute__((ext_vector_type(4)));
+                    pool_u4 v0 = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
+                    const bool in_lds = cur < n_cached;
+                    if (in_lds) {
+                        typedef const pool_u4 __attribute__((address_space(3)))* lds_words;
+                        const lds_words q = (lds_words)&L.nodes[cur * 5];
+                        v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
+                    }
+                    __asm__ volatile("" ::: "memory");
+                    if (!in_lds) {
+                        typedef const pool_u4 __attribute__((address_space(1)))* mem_words;
+                        const mem_words q = (mem_words)(nodes + cur);
+                        v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
+                    }
+                    const uint4 w0 = make_uint4(v0.x, v0.y, v0.z, v0.w), w1 = make_uint4(v1.x, v1.y, v1.z, v1.w), w2 = make_uint4(v2.x, v2.y, v2.z, v2.w),
+                                w3 = make_uint4(v3.x, v3.y, v3.z, v3.w);
+                    const CwHits h = cw_step_words(w0, w1, w2, w3, rf, limit);
 #else
-                        const CwHits h = cw_step(nodes + cur, rf, limit);        // (a global load: a pointer that may be LDS or memory is a flat one)
+                    const CwHits h = cw_step(nodes + cur, rf, limit);        // (a global load: a pointer that may be LDS or memory is a flat one)
 #endif
 
-                        junk += pf; pf = 0;
+                    junk += pf; pf = 0;
 #if MCPT_POOL_FASTPUSH
-                        // The children come back sorted with the culled ones last: n hits, the n - 1 farther ones go on the stack, farthest
-                        // first.  When every lane's pushes stay in the LDS part of its stack (nine steps in ten) they are three predicated
-                        // stores at computed positions -- no branch per push, none between LDS and the spill area.
-                        const int n_hit = (h.ref[0] != MCPT_FAST_EMPTY) + (h.ref[1] != MCPT_FAST_EMPTY) + (h.ref[2] != MCPT_FAST_EMPTY) + (h.ref[3] != MCPT_FAST_EMPTY);
-                        if (!__ballot(sp + n_hit - 1 > SCAP)) {
-                            int* const col = &L.stack[k * 64 + lane];
-                            if (n_hit >= 4) col[sp * (KT * 64)] = h.ref[3];
-                            if (n_hit >= 3) col[(sp + n_hit - 3) * (KT * 64)] = h.ref[2];
-                            if (n_hit >= 2) col[(sp + n_hit - 2) * (KT * 64)] = h.ref[1];
-                            sp += n_hit > 1 ? n_hit - 1 : 0;
-                        } else {
-                            if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
-                            if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
-                            if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
-                        }
-#else
+                    // The children come back sorted with the culled ones last: n hits, the n - 1 farther ones go on the stack, farthest
+                    // first.  When every lane's pushes stay in the LDS part of its stack (nine steps in ten) they are three predicated
+                    // stores at computed positions -- no branch per push, none between LDS and the spill area.
+                    const int n_hit = (h.ref[0] != MCPT_FAST_EMPTY) + (h.ref[1] != MCPT_FAST_EMPTY) + (h.ref[2] != MCPT_FAST_EMPTY) + (h.ref[3] != MCPT_FAST_EMPTY);
+                    if (!__ballot(sp + n_hit - 1 > SCAP)) {
+                        int* const col = &L.stack[k * 64 + lane];
+                        if (n_hit >= 4) col[sp * (KT * 64)] = h.ref[3];
+                        if (n_hit >= 3) col[(sp + n_hit - 3) * (KT * 64)] = h.ref[2];
+                        if (n_hit >= 2) col[(sp + n_hit - 2) * (KT * 64)] = h.ref[1];
+                        sp += n_hit > 1 ? n_hit - 1 : 0;
+                    } else {
                         if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
                         if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
                         if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
-#endif
-                        int nxt = h.ref[0];
-#if MCPT_POOL_FASTPUSH
-                        {
-                            const bool pop = nxt == MCPT_FAST_EMPTY && sp > 0;
-                            if (pop) sp--;
-                            if (!__ballot(pop && sp >= SCAP)) { if (pop) { nxt = L.stack[(sp * KT + k) * 64 + lane]; __asm__ volatile("" : "+v"(nxt)); } }      // (an LDS read, not a flat one)
-                            else if (pop) nxt = st_get(sp, k);
-                        }
-#else
-                        if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = st_get(sp, k); }
-#endif
-                        const bool node = nxt >= 0, none = nxt == MCPT_FAST_EMPTY;
-                        const int ref = -1 - nxt;
-                        const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
-                        if (!none) { touch_next(node, first, cnt); L.cur[idx] = first; }
-                        spf = (spf & 0xff00) | sp | ((!node && !none) ? cnt << 16 : 0);
-                        L.spf[idx] = spf;
-                        nc = node ? C_INNER : (none ? C_FIN : C_LEAF);
-                        (void)cur;
                     }
+#else
+                    if (h.ref[3] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[3]); sp++; }
+                    if (h.ref[2] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[2]); sp++; }
+                    if (h.ref[1] != MCPT_FAST_EMPTY) { st_put(sp, k, h.ref[1]); sp++; }
+#endif
+                    int nxt = h.ref[0];
+#if MCPT_POOL_FASTPUSH
+                    {
+                        const bool pop = nxt == MCPT_FAST_EMPTY && sp > 0;
+                        if (pop) sp--;
+                        if (!__ballot(pop && sp >= SCAP)) { if (pop) { nxt = L.stack[(sp * KT + k) * 64 + lane]; __asm__ volatile("" : "+v"(nxt)); } }      // (an LDS read, not a flat one)
+                        else if (pop) nxt = st_get(sp, k);
+                    }
+#else
+                    if (nxt == MCPT_FAST_EMPTY && sp > 0) { sp--; nxt = st_get(sp, k); }
+#endif
+                    const bool node = nxt >= 0, none = nxt == MCPT_FAST_EMPTY;
+                    const int ref = -1 - nxt;
+                    const int first = node ? nxt : ref >> 4, cnt = (ref & 7) + 1;
+                    if (!none) { touch_next(node, first, cnt); L.cur[idx] = first; }
+                    spf = (spf & 0xff00) | sp | ((!node && !none) ? cnt << 16 : 0);
+                    L.spf[idx] = spf;
+                    nc = node ? C_INNER : (none ? C_FIN : C_LEAF);
                 }
             }
             c_nodes += (unsigned int)(n_have - __popcll(__ballot(refused)));
