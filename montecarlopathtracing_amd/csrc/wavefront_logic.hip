@@ -91,7 +91,8 @@ __device__ __forceinline__ void wf_shade_vertex(const DScene& S, const WfArgs& a
 // lead to a surface that is not an emitter -- and parks the survivors in a ring in LDS: position, leaf, radiance (32 bytes).  It SHADES
 // in rounds of 256 vertices taken off the ring, every wave full, as soon as 256 are there (and what is left at the end): the words the
 // next vertex is made of (sample id, throughput, the bounce ray it was reached by) are read from the position then -- for the
-// survivors only, which is a fifth less to read than when every position brought them along.  One barrier per resolve round (the
+// survivors only (the bytes moved stay what they were: a survivor's words share their 128-byte lines with the dead positions').  One
+// barrier per resolve round (the
 // block-wide prefix), one per shade round (ring and output base visible); a block's output positions are one atomic per shade round.
 // Ring slots are written after the barrier of a resolve round, which every wave reaches only after its reads of the shade round
 // before: no slot is overwritten while it is read.
