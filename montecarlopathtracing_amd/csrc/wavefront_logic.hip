@@ -18,6 +18,22 @@
 
 namespace mcpt {
 
+// The path state is a stream: every word is read once and written once per pass.  The logic kernel's accesses to it are marked
+// non-temporal, so that they do not push the scene's triangles and shading records -- which the shade rounds gather at random -- out of
+// L1 / L2 (round 4: -1 % of the frame on four scenes; MCPT_LOGIC_NT = 0 for A/B runs).
+#ifndef MCPT_LOGIC_NT
+#define MCPT_LOGIC_NT 1
+#endif
+#if MCPT_LOGIC_NT
+template <class T> __device__ __forceinline__ T sld(const T* p) { return __builtin_nontemporal_load(p); }
+template <class T> __device__ __forceinline__ void sst(T* p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ __forceinline__ T sld(const T* p) { return *p; }
+template <class T> __device__ __forceinline__ void sst(T* p, T v) { *p = v; }
+#endif
+__device__ __forceinline__ V3 sldc(const double* __restrict__ a, long long cap, long long i) { return mk(sld(a + i), sld(a + cap + i), sld(a + 2 * cap + i)); }
+__device__ __forceinline__ void sstc(double* __restrict__ a, long long cap, long long i, V3 v) { sst(a + i, v.x); sst(a + cap + i, v.y); sst(a + 2 * cap + i, v.z); }
+
 #ifndef MCPT_FINISH_WAVES
 #define MCPT_FINISH_WAVES 2  /* blocks of the finishing kernel per CU the compiler plans for: 2 = 256 registers per lane (76 bytes of them in scratch memory), 1 = 512 */
 #endif
@@ -44,8 +60,8 @@ __device__ __forceinline__ void wf_shade_vertex(const DScene& S, const WfArgs& a
     const int nl = a.nl;
     const bool folded = nl == 1;
     const uint32_t depth = (uint32_t)a.depth;
-    a.out.id[j] = id;
-    if (!FIRST) { stc(a.out.L, cap, j, L); stc(a.out.p, cap, j, p); }       // first pass: L = 0; p is the pixel's primary hit (a.hits)
+    sst(a.out.id + j, id);
+    if (!FIRST) { sstc(a.out.L, cap, j, L); sstc(a.out.p, cap, j, p); }       // first pass: L = 0; p is the pixel's primary hit (a.hits)
     const DMaterial* m = S.materials + (FIRST ? mat_first : S.tris[leaf].material);
     V3 pn = pn_first, kd = kd_first;
     if (!FIRST) vertex_surface(S, leaf, p, m, pn, kd);
@@ -59,10 +75,10 @@ __device__ __forceinline__ void wf_shade_vertex(const DScene& S, const WfArgs& a
     {
         V3 nd = mk(0, 0, 0), wgt = mk(1, 1, 1);
         const int btype = bounce_sample(key, depth, nl, m, dir, pn, kd, nd, wgt);
-        if (btype >= 0) { stc(a.out.bdir, cap, j, nd); ls.bounce++; }
-        a.out.btype[j] = btype;
-        if (folded) stc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
-        else { stc(a.out.w, cap, j, wgt); if (!FIRST) stc(a.out.T, cap, j, T); }
+        if (btype >= 0) { sstc(a.out.bdir, cap, j, nd); ls.bounce++; }
+        sst(a.out.btype + j, btype);
+        if (folded) sstc(a.out.T, cap, j, mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR));
+        else { sstc(a.out.w, cap, j, wgt); if (!FIRST) sstc(a.out.T, cap, j, T); }
     }
 
     int sample_mat = -1;
@@ -70,11 +86,11 @@ __device__ __forceinline__ void wf_shade_vertex(const DScene& S, const WfArgs& a
         V3 direction, c;
         const int expect = light_sample(S, key, depth, l, p, pn, kd, sample_mat, direction, c);
         if (expect != -2) {
-            stc(a.out.c + (long long)l * 3 * cap, cap, j, folded ? mk(T.x * c.x, T.y * c.y, T.z * c.z) : c);
-            stc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);       // origin p + direction * 0.01: WfRaySource
+            sstc(a.out.c + (long long)l * 3 * cap, cap, j, folded ? mk(T.x * c.x, T.y * c.y, T.z * c.z) : c);
+            sstc(a.rays.d + (long long)l * 3 * cap, cap, j, direction);       // origin p + direction * 0.01: WfRaySource
             ls.shadow++;
         } else ls.skipped++;
-        a.out.expect[(long long)l * cap + j] = expect;
+        sst(a.out.expect + ((long long)l * cap + j), expect);
     }
 }
 
@@ -183,17 +199,17 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
                     pos[u] = base + threadIdx.x;
                     base += (long long)gridDim.x * 256;
                     const long long i = pos[u] < n_prev ? pos[u] : 0;       // (past the end: position 0's words, not used)
-                    id[u] = a.in.id[i]; bt[u] = a.in.btype[i]; hl[u] = a.in.hit_leaf[i];
+                    id[u] = sld(a.in.id + i); bt[u] = sld(a.in.btype + i); hl[u] = sld(a.in.hit_leaf + i);
                     // folded (one light): in.T already is the throughput after the bounce and in.c is T * c (see the stores of
                     // wf_shade_vertex) -- the resolve needs T only where a specular chain ends on an emitter
                     T[u] = mk(1, 1, 1); L[u] = mk(0, 0, 0); wgt[u] = mk(1, 1, 1); L_dir[u] = mk(0, 0, 0);
-                    if (!folded && depth > 1) T[u] = ldc(a.in.T, cap, i);
-                    if (depth > 1) L[u] = ldc(a.in.L, cap, i);
-                    if (!folded) wgt[u] = ldc(a.in.w, cap, i);
+                    if (!folded && depth > 1) T[u] = sldc(a.in.T, cap, i);
+                    if (depth > 1) L[u] = sldc(a.in.L, cap, i);
+                    if (!folded) wgt[u] = sldc(a.in.w, cap, i);
                     for (int l = 0; l < nl; l++) {
-                        const int expect = a.in.expect[(long long)l * cap + i];
-                        const int hm = a.in.hit_mat[(long long)l * cap + i];
-                        const V3 c = ldc(a.in.c + (long long)l * 3 * cap, cap, i);
+                        const int expect = sld(a.in.expect + ((long long)l * cap + i));
+                        const int hm = sld(a.in.hit_mat + ((long long)l * cap + i));
+                        const V3 c = sldc(a.in.c + (long long)l * 3 * cap, cap, i);
                         if (expect == -2) continue;
                         const bool vis = hm == expect;
                         L_dir[u].x += vis ? c.x : c.x * 0.0;
@@ -218,13 +234,13 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
                             if (hl[u] & MCPT_HIT_EMITTER) {                              // emitter: pathTracing.cpp:141-144
                                 if ((bt[u] & 7) != RT_DIFFUSE) {
                                     const DMaterial* m = S.materials + S.tris[hl[u] & MCPT_HIT_LEAF_MASK].material;
-                                    if (folded) T[u] = ldc(a.in.T, cap, pos[u]);
+                                    if (folded) T[u] = sldc(a.in.T, cap, pos[u]);
                                     const V3 rad = ld3(S.lights[m->light].radiance);
                                     L[u] = L[u] + mk(T[u].x * rad.x, T[u].y * rad.y, T[u].z * rad.z);
                                 }
                             } else alive[u] = true;
                         }
-                        if (!alive[u]) { a.rad[(size_t)id[u] * 3] = L[u].x; a.rad[(size_t)id[u] * 3 + 1] = L[u].y; a.rad[(size_t)id[u] * 3 + 2] = L[u].z; }
+                        if (!alive[u]) { sst(a.rad + (size_t)id[u] * 3, L[u].x); sst(a.rad + (size_t)id[u] * 3 + 1, L[u].y); sst(a.rad + (size_t)id[u] * 3 + 2, L[u].z); }
                     }
                 }
                 MCPT_LSTAMP(0)
@@ -268,16 +284,16 @@ __global__ void __launch_bounds__(256, FIRST ? MCPT_LOGIC_WAVES_FIRST : MCPT_LOG
                 const V3 L = mk(ring_L[0][s], ring_L[1][s], ring_L[2][s]);
                 const long long j = (long long)block_base[bturn] + threadIdx.x;
                 // the sample, its throughput and the bounce ray that reached this vertex, from the position
-                const int id = a.in.id[i];
-                const int bt = a.in.btype[i];
+                const int id = sld(a.in.id + i);
+                const int bt = sld(a.in.btype + i);
                 V3 T = mk(1, 1, 1);
-                if (depth > 1 || folded) T = ldc(a.in.T, cap, i);
-                if (!folded) { const V3 wgt = ldc(a.in.w, cap, i); T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR); }
-                const V3 bd = ldc(a.in.bdir, cap, i);
+                if (depth > 1 || folded) T = sldc(a.in.T, cap, i);
+                if (!folded) { const V3 wgt = sldc(a.in.w, cap, i); T = mk(T.x * wgt.x * MCPT_INV_P_RR, T.y * wgt.y * MCPT_INV_P_RR, T.z * wgt.z * MCPT_INV_P_RR); }
+                const V3 bd = sldc(a.in.bdir, cap, i);
                 // the vertex the bounce ray left from: the pixel's primary hit after the first pass, in.p afterwards
                 V3 pv;
                 if (depth == 1) { const PrimaryHit* ph = a.hits + (a.first_slot + id / a.spp); pv = mk(ph->p[0], ph->p[1], ph->p[2]); }
-                else pv = ldc(a.in.p, cap, i);
+                else pv = sldc(a.in.p, cap, i);
                 // the hit point of the bounce ray, as the reference's test formed it when the trace kernel accepted the triangle
                 // (sceneManagement.cpp:318-320: t = ((v1 - o) . n) / (n . d), p = o + d t; same operands, same operations)
                 const V3 ro = (bt & MCPT_BT_NO_OFFSET) ? pv : pv + bd * 0.01;

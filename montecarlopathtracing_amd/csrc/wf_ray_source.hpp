@@ -70,6 +70,19 @@ template <class T> __device__ __forceinline__ T __attribute__((address_space(1))
 {
     return (T __attribute__((address_space(1)))*)p;
 }
+// MCPT_TRACE_NT = 1: the trace kernels' reads of the path state (a stream: every ray is fetched once) and their answers go past the caches'
+// normal replacement (non-temporal), so that they do not push nodes and triangles out of L1 / L2.  Measured in round 4: no difference
+// (7.16 against 7.13 ms per launch; the logic kernel's own accesses, wavefront_logic.hip, are where the hint pays).
+#ifndef MCPT_TRACE_NT
+#define MCPT_TRACE_NT 0
+#endif
+#if MCPT_TRACE_NT
+template <class P> __device__ __forceinline__ auto wf_sld(P p) { return __builtin_nontemporal_load(p); }
+template <class P, class T> __device__ __forceinline__ void wf_sst(P p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class P> __device__ __forceinline__ auto wf_sld(P p) { return *p; }
+template <class P, class T> __device__ __forceinline__ void wf_sst(P p, T v) { *p = v; }
+#endif
 struct WfRaySourceK {
     static constexpr bool kWantsPoint = false;
     WfArgsKernarg ap;
@@ -89,17 +102,17 @@ struct WfRaySourceK {
         const WfArgsKernarg A = args();
         const long long cap = A->cap;
         const bool bounce = l == nl;
-        const int flag = bounce ? wf_glob(A->out.btype)[j] : wf_glob(A->out.expect)[(long long)l * cap + j];
+        const int flag = bounce ? wf_sld(wf_glob(A->out.btype) + j) : wf_sld(wf_glob(A->out.expect) + ((long long)l * cap + j));
         V3 p;
         if (A->depth == 0) {
             const auto* ph = wf_glob(A->hits) + (A->first_slot + wf_glob(A->out.id)[j] / A->spp);
             p = mk(ph->p[0], ph->p[1], ph->p[2]);
         } else {
             const auto* g = wf_glob(A->out.p);
-            p = mk(g[j], g[cap + j], g[2 * cap + j]);
+            p = mk(wf_sld(g + j), wf_sld(g + cap + j), wf_sld(g + 2 * cap + j));
         }
         const auto* d = wf_glob(bounce ? A->out.bdir : A->rays.d + (long long)l * 3 * cap);
-        r.d = mk(d[j], d[cap + j], d[2 * cap + j]);
+        r.d = mk(wf_sld(d + j), wf_sld(d + cap + j), wf_sld(d + 2 * cap + j));
         r.o = (bounce && (flag & MCPT_BT_NO_OFFSET)) ? p : p + r.d * 0.01;
         return bounce ? flag >= 0 : flag != -2;
     }
@@ -111,9 +124,9 @@ struct WfRaySourceK {
         if (l == nl) {
             int v = -1;
             if (ok) { const int mat = h.mat >= 0 ? h.mat : wf_glob(A->tris)[h.leaf].material; v = h.leaf | (wf_glob(A->materials)[mat].light >= 0 ? MCPT_HIT_EMITTER : 0); }
-            wf_glob_mut(A->out.hit_leaf)[j] = v;
+            wf_sst(wf_glob_mut(A->out.hit_leaf) + j, v);
         }
-        else wf_glob_mut(A->out.hit_mat)[(long long)l * A->cap + j] = ok ? (h.mat >= 0 ? h.mat : wf_glob(A->tris)[h.leaf].material) : -1;
+        else wf_sst(wf_glob_mut(A->out.hit_mat) + ((long long)l * A->cap + j), ok ? (h.mat >= 0 ? h.mat : wf_glob(A->tris)[h.leaf].material) : -1);
     }
 };
 
