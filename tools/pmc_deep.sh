@@ -1,5 +1,5 @@
 #!/bin/bash
-# The wider hardware-counter set behind profiles/r04_pool_counters_deep.txt: seven rocprofv3 --pmc passes (no other tracing) over one frame
+# The wider hardware-counter set behind profiles/r04_pool_counters_deep.txt: six rocprofv3 --pmc passes (no other tracing) over one frame
 # of the default bench, summarised per kernel.  usage (on the GPU box, from the repo root):  bash tools/pmc_deep.sh <outdir> [kernel substring]
 set +e
 out=${1:-gpurun_out/pmc_deep}; kern=${2:-k_wf_trace_pool}
